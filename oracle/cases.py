@@ -1,0 +1,63 @@
+"""Seeded synthetic parity cases shared by oracle/make_golden.py and tests/.  TEST INFRASTRUCTURE ONLY."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import nerface_oracle as O
+
+
+def ray_subset(height, width, frame, n_rays, seed, dtype=torch.float32):
+    """n_rays pixels drawn (seeded, without replacement) from frame `frame` of the synthetic scene."""
+    ro, rd = O.ray_bundle(height, width, O.INTRINSICS, O.frame_pose(frame, dtype))
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(height * width, generator=g)[:n_rays]
+    bg = O.synthetic_image(height, width, 7, dtype).reshape(-1, 3)[idx]
+    tgt = O.synthetic_image(height, width, 11, dtype).reshape(-1, 3)[idx]
+    return ro.reshape(-1, 3)[idx].contiguous(), rd.reshape(-1, 3)[idx].contiguous(), bg.contiguous(), tgt.contiguous(), idx
+
+
+def randoms(n_rays, n_coarse, n_fine, seed=123, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    t_rand = torch.rand((n_rays, n_coarse), generator=g, dtype=dtype)
+    noise_c = torch.randn((n_rays, n_coarse), generator=g, dtype=dtype)
+    u = torch.rand((n_rays, n_fine), generator=g, dtype=dtype)
+    noise_f = torch.randn((n_rays, n_coarse + n_fine), generator=g, dtype=dtype)
+    return t_rand, noise_c, u, noise_f
+
+
+CASES = {
+    # name: (frame, n_rays, n_coarse, n_fine, stochastic, noise_std)
+    "eval_det_64_128": dict(frame=3, n_rays=40, n_coarse=64, n_fine=128, stochastic=False, noise_std=0.0),
+    "train_rand_64_64": dict(frame=17, n_rays=24, n_coarse=64, n_fine=64, stochastic=True, noise_std=0.1),
+    "ragged_5_7": dict(frame=5, n_rays=7, n_coarse=5, n_fine=7, stochastic=True, noise_std=0.0),
+    "coarse_only": dict(frame=8, n_rays=9, n_coarse=16, n_fine=0, stochastic=False, noise_std=0.0),
+}
+
+
+def build_case(name, dtype=torch.float32):
+    c = dict(CASES[name])
+    ro, rd, bg, tgt, idx = ray_subset(512, 512, c["frame"], c["n_rays"], seed=31 + c["frame"], dtype=dtype)
+    expr, latent = O.frame_conditioning(c["frame"], dtype)
+    c.update(ro=ro, rd=rd, bg=bg, tgt=tgt, idx=idx, expr=expr, latent=latent)
+    if c["stochastic"]:
+        t_rand, noise_c, u, noise_f = randoms(c["n_rays"], c["n_coarse"], max(c["n_fine"], 1), dtype=dtype)
+        c.update(t_rand=t_rand, u=u if c["n_fine"] > 0 else None,
+                 noise_c=noise_c * c["noise_std"] if c["noise_std"] > 0 else None,
+                 noise_f=noise_f * c["noise_std"] if c["noise_std"] > 0 else None,
+                 noise_c_unit=noise_c, noise_f_unit=noise_f)
+    else:
+        c.update(t_rand=None, u=None, noise_c=None, noise_f=None)
+    c["p_coarse"] = O.init_paper_params(0, dtype)
+    c["p_fine"] = O.init_paper_params(1, dtype)
+    return c
+
+
+def run_oracle(c, stages=None):
+    return O.render_rays(c["p_coarse"], c["p_fine"], c["ro"], c["rd"], c["expr"], c["latent"], c["bg"],
+                         O.NEAR, O.FAR, c["n_coarse"], c["n_fine"], t_rand=c["t_rand"], noise_c=c["noise_c"],
+                         u=c["u"], noise_f=c["noise_f"], stages=stages)
+
+
+def params_checksum(p) -> float:
+    return float(sum(float(v.double().abs().sum()) * (i + 1) for i, (k, v) in enumerate(sorted(p.items()))))

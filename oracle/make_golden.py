@@ -1,0 +1,155 @@
+"""Generate tests/golden/*.npz by running the UNMODIFIED reference on CPU.  TEST INFRASTRUCTURE ONLY.
+
+Run inside the build container (where /root/reference exists):   python -m oracle.make_golden
+The fixtures hold reference OUTPUTS for the seeded synthetic cases of oracle/cases.py; inputs and
+weights are regenerated from seeds by the tests (a weight checksum is stored to detect RNG drift).
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cases as C                      # noqa: E402
+from oracle import nerface_oracle as O             # noqa: E402
+from oracle import ref_import as RI                # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def ref_options(ref, n_coarse, n_fine, perturb, noise_std):
+    mode = dict(num_coarse=n_coarse, num_fine=n_fine, chunksize=65536, perturb=perturb, lindisp=False,
+                radiance_field_noise_std=noise_std, white_background=False, num_random_rays=2048)
+    return ref.CfgNode(dict(nerf=dict(use_viewdirs=True, encode_position_fn="positional_encoding",
+                                      encode_direction_fn="positional_encoding", train=dict(mode), validation=dict(mode)),
+                            dataset=dict(no_ndc=True, near=O.NEAR, far=O.FAR)))
+
+
+def ref_model(ref, params):
+    m = ref.models.ConditionalBlendshapePaperNeRFModel(
+        num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False,
+        use_viewdirs=True, num_layers=4, hidden_size=256, include_expression=True)
+    m.load_state_dict(params)
+    return m
+
+
+def run_reference(ref, c, grad=False):
+    mc, mf = ref_model(ref, c["p_coarse"]), ref_model(ref, c["p_fine"]) if c["n_fine"] > 0 else None
+    opt = ref_options(ref, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"])
+    enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    rands, randns = [], []
+    if c["stochastic"]:
+        rands.append(c["t_rand"])
+        if c["noise_std"] > 0:
+            randns.append(c["noise_c_unit"])
+        if c["n_fine"] > 0:
+            rands.append(c["u"])
+            if c["noise_std"] > 0:
+                randns.append(c["noise_f_unit"])
+    latent = c["latent"].clone().requires_grad_(grad)
+    ctx = torch.enable_grad() if grad else torch.no_grad()
+    with ctx, RI.injected_random(rands, randns), RI.relu_clone_shim(ref):
+        out = ref.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"], c["rd"], opt, mode="train",
+                                       encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                       expressions=c["expr"], background_prior=c["bg"], latent_code=latent)
+        grads = None
+        if grad:
+            loss = O.train_loss(out[0], out[3], c["tgt"], latent)
+            loss.backward()
+            grads = {"latent": latent.grad.clone(), "loss": loss.detach().clone()}
+            for tag, m in (("coarse", mc), ("fine", mf)):
+                for k, v in m.named_parameters():
+                    grads[f"{tag}.{k}"] = None if v.grad is None else v.grad.clone()
+    return out, grads
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    ref = RI.import_reference()
+    torch.set_num_threads(8)
+    names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
+    for name in C.CASES:
+        c = C.build_case(name)
+        out_ref, _ = run_reference(ref, c)
+        st = {}
+        out_or = C.run_oracle(c, st)
+        blob = {"params_checksum": np.float64(C.params_checksum(c["p_coarse"]) + C.params_checksum(c["p_fine"]))}
+        for n, a, b in zip(names7, out_ref, out_or):
+            if a is None:
+                assert b is None
+                continue
+            exact = torch.equal(a, b)
+            print(f"[{name}] {n}: exact={exact} max|d|={float((a - b).abs().max()):.3e}")
+            blob[n] = a.numpy()
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
+
+    # gradient fixture (reference autograd with the Q9 shim)
+    c = C.build_case("train_rand_64_64")
+    out_ref, g = run_reference(ref, c, grad=True)
+    blob = {"loss": g["loss"].numpy(), "latent": g["latent"].numpy()}
+    for k, v in g.items():
+        if k in ("loss", "latent"):
+            continue
+        if v is None:
+            blob["none:" + k] = np.zeros(0, np.float32)
+        else:
+            blob["norm:" + k] = np.float64(v.double().norm())
+            if v.numel() <= 1024:
+                blob["full:" + k] = v.numpy()
+            else:
+                blob["head:" + k] = v.reshape(-1)[:257].numpy()
+    np.savez_compressed(os.path.join(OUT, "train_rand_64_64_grads.npz"), **blob)
+    print("grad fixture: loss", float(g["loss"]), "latent |g|", float(g["latent"].norm()))
+
+    # ray bundle (non-square, full) + bit-exactness of the oracle restatement
+    pose = O.frame_pose(42)
+    ro, rd = ref.get_ray_bundle(37, 53, O.INTRINSICS, pose)
+    ro2, rd2 = O.ray_bundle(37, 53, O.INTRINSICS, pose)
+    print("ray_bundle exact:", torch.equal(rd, rd2), torch.equal(ro, ro2))
+    ro_s, rd_s = ref.get_ray_bundle(24, 24, torch.tensor(138.88 * 24 / 100.0), pose)     # scalar-focal fallback (H:109)
+    np.savez_compressed(os.path.join(OUT, "ray_bundle.npz"), rd=rd.numpy(), ro=ro.numpy(), rd_scalar=rd_s.numpy())
+
+    # positional encoding + sample_pdf edge cases
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((33, 3), generator=g) - 0.5) * 1.6
+    pe10 = ref.positional_encoding(x, 10, True, True)
+    pe4 = ref.positional_encoding(x, 4, False, True)
+    tu = sys.modules["_ref_nerf.train_utils"]
+    bins = torch.sort(torch.rand((6, 63), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    w = torch.rand((6, 62), generator=g)
+    w[1] = 0.0                      # all-zero weights -> uniform pdf
+    w[2, :30] = 0.0
+    w[2, 31:] = 0.0                 # single spike
+    w[3] = 1.0                      # uniform
+    uu = torch.rand((6, 128), generator=g)
+    uu[4, :4] = torch.tensor([0.0, 1.0, 0.5, 0.999999])
+    with RI.injected_random([uu], []):
+        zs_rand = tu.sample_pdf(bins, w, 128, det=False)
+    zs_det = tu.sample_pdf(bins, w, 128, det=True)
+    np.savez_compressed(os.path.join(OUT, "pe_pdf.npz"), x=x.numpy(), pe10=pe10.numpy(), pe4=pe4.numpy(),
+                        bins=bins.numpy(), w=w.numpy(), u=uu.numpy(), zs_rand=zs_rand.numpy(), zs_det=zs_det.numpy())
+
+    # tiny_nerf (BASELINE config 1): 64x64, 32 samples, 3-layer 128-wide MLP, coarse only
+    TN = RI.import_reference_tiny()
+    tp = O.tiny_init_params(9458)
+    tm = TN.VeryTinyNerfModel(num_encoding_functions=10)
+    tm.load_state_dict(tp)
+    pose = O.frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    jit = torch.rand((64, 64, 32), generator=torch.Generator().manual_seed(77))
+    with torch.no_grad(), RI.injected_random([jit], []):
+        rgb = TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32,
+                                          lambda x, n: ref.positional_encoding(x, n), ref.get_minibatches, 16384, tm, 10)
+    rgb2, _, _ = O.tiny_render(tp, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+    print("tiny exact:", torch.equal(rgb, rgb2), float((rgb - rgb2).abs().max()))
+    np.savez_compressed(os.path.join(OUT, "tiny_64x64x32.npz"), rgb=rgb.numpy())
+
+
+if __name__ == "__main__":
+    main()
