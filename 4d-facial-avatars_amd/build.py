@@ -1,0 +1,69 @@
+"""Build libnerface_hip.so (gfx950) in-tree with hipcc.  Usage: python 4d-facial-avatars_amd/build.py [--force]
+
+The library is plain C ABI (include/nerface_hip.h); it links only against the HIP runtime, which the
+host process (PyTorch-ROCm) has already loaded when the Python binding dlopens it.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc")
+OUT_DIR = os.path.join(HERE, "lib")
+OUT = os.path.join(OUT_DIR, "libnerface_hip.so")
+SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
+         "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (need ROCm's hipcc to build libnerface_hip.so)")
+
+
+def _stale() -> bool:
+    if not os.path.exists(OUT):
+        return True
+    t = os.path.getmtime(OUT)
+    deps = [os.path.join(SRC, f) for f in os.listdir(SRC)] + [os.path.join(HERE, "..", "include", "nerface_hip.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    if not force and not _stale():
+        return OUT
+    os.makedirs(OUT_DIR, exist_ok=True)
+    objs = []
+    cc = _hipcc()
+    procs = []
+    for s in SOURCES:
+        src = os.path.join(SRC, s)
+        if not os.path.exists(src):
+            continue
+        obj = os.path.join(OUT_DIR, s.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append((s, subprocess.Popen([cc, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
+        if verbose and out.strip():
+            print(out.decode())
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if r.returncode != 0:
+        raise RuntimeError("link failed:\n" + r.stdout.decode())
+    for o in objs:
+        os.remove(o)
+    if verbose:
+        print("built", OUT)
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

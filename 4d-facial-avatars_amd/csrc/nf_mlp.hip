@@ -1,0 +1,425 @@
+// K4: fused forward of ConditionalBlendshapePaperNeRFModel (reference nerf/models.py:189-261) together
+// with run_network's input assembly (reference nerf/train_utils.py:9-33,78): pts = ro + rd*z, both
+// positional encodings, the [xyz | expr | latent] / skip / [feat | dirs] concatenations and all 11
+// live Linear layers -- one launch, nothing but (ro, rd, z) read and 16 B/point written.
+//
+// Structure (gfx950, exact-f32 MFMA v_mfma_f32_16x16x4_f32; see nf_mlp_layout.h for the fragment maths):
+//   * one wavefront owns 16*NT consecutive points for the whole network; waves never communicate, so
+//     the kernel has no barrier at all (block = 4 independent waves, one per SIMD, 512-VGPR budget);
+//   * the layer output of a wave (NT x 16 tiles x 4 regs) is accumulated in registers, written once to
+//     the wave's private LDS slab as 16-byte fragments (XOR-swizzled, conflict-free) and read back as
+//     the next layer's B fragments -- one ds_read_b128 per 64 MFMAs;
+//   * weights stream from L2 (2.2 MB image, shared by every workgroup) as perfectly coalesced 1-KiB
+//     wave loads, one K-chunk ahead of the MFMAs that consume them (register double buffer);
+//   * the 63-wide positional encoding lives in registers in B-fragment order (one sincosf per two
+//     slots) and is consumed twice (layers_xyz.0 and the skip input of layers_xyz.3);
+//   * the per-call constant input columns (expression, latent code, PE(near), PE(far)) never enter
+//     the GEMMs: nf_paper_condition folds them into bias vectors (the `cond` table).
+#include <vector>
+#include <mutex>
+#include "nf_common.h"
+#include "nf_mlp_layout.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NF_MLP_WAVES 4
+
+// =================================================================================================
+// pack: gather the 26 nn.Parameter storages into the fragment-ordered image
+// =================================================================================================
+struct NfParamPtrs { const float* p[NF_PAPER_NUM_PARAMS]; };
+
+static const uint32_t NF_ZERO_CODE = 0xFF000000u;
+static inline uint32_t nf_code(int tensor, int row, int col, int ncols) { return ((uint32_t)tensor << 24) | (uint32_t)(row * ncols + col); }
+
+// state_dict ids (NF_PAPER_NUM_PARAMS order)
+enum { ID_XYZ0_W = 0, ID_XYZ0_B = 1, ID_FEAT_W = 12, ID_FEAT_B = 13, ID_ALPHA_W = 14, ID_ALPHA_B = 15, ID_DIR0_W = 16,
+       ID_DIR0_B = 17, ID_RGB_W = 24, ID_RGB_B = 25 };
+
+// Fill one MFMA layer section.  col_of(slot) -> reference column of `tensor` (or -1 = zero);
+// rows >= n_out are zero, except that `alpha_row` (if >= 0) is served from fc_alpha.weight.
+template <class ColFn>
+static void nf_fill_layer(std::vector<uint32_t>& t, int off, int nk, int no_tiles, int tensor, int n_out, int n_cols,
+                          ColFn col_of, int alpha_row = -1) {
+    for (int ni = 0; ni < nk; ++ni)
+        for (int no = 0; no < no_tiles; ++no)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int g = lane >> 4, i = lane & 15;
+                    const int n = 16 * no + i, slot = 16 * ni + 4 * g + r;
+                    uint32_t code = NF_ZERO_CODE;
+                    if (n < n_out) {
+                        const int col = col_of(slot);
+                        if (col >= 0) code = nf_code(tensor, n, col, n_cols);
+                    } else if (n == alpha_row) {
+                        if (slot < 256) code = nf_code(ID_ALPHA_W, 0, slot, 256);   // fc_alpha reads feat only
+                    }
+                    t[(size_t)off + ((size_t)(ni * no_tiles + no) * 64 + lane) * 4 + r] = code;
+                }
+}
+
+static void nf_build_gather_table(std::vector<uint32_t>& t) {
+    using namespace nfl;
+    t.assign(PACKED_FLOATS, NF_ZERO_CODE);
+    auto ident = [](int slot) { return slot; };
+    nf_fill_layer(t, OFF_L0, 4, 16, 0, 256, 171, [](int s) { return pe_slot_to_col(s); });
+    nf_fill_layer(t, OFF_L1, 16, 16, 2, 256, 256, ident);
+    nf_fill_layer(t, OFF_L2, 16, 16, 4, 256, 256, ident);
+    nf_fill_layer(t, OFF_L3, 20, 16, 6, 256, 427, [](int s) { return s < 64 ? pe_slot_to_col(s) : 171 + (s - 64); });
+    nf_fill_layer(t, OFF_L4, 16, 16, 8, 256, 256, ident);
+    nf_fill_layer(t, OFF_L5, 16, 16, 10, 256, 256, ident);
+    nf_fill_layer(t, OFF_FEAT, 16, 16, ID_FEAT_W, 256, 256, ident);
+    // layers_dir.0: slots 0..255 = feat; chunk 16: lane group g holds (sin, cos)(rd_z * 2^g) at r = 0, 1
+    nf_fill_layer(t, OFF_D0, 17, 9, ID_DIR0_W, 128, 280,
+                  [](int s) {
+                      if (s < 256) return s;
+                      const int g = ((s - 256) >> 2) & 3, r = (s - 256) & 3;
+                      return r < 2 ? 256 + 6 * g + 3 * r : -1;
+                  },
+                  /*alpha_row=*/128);
+    nf_fill_layer(t, OFF_D1, 8, 8, 18, 128, 128, ident);
+    nf_fill_layer(t, OFF_D2, 8, 8, 20, 128, 128, ident);
+    nf_fill_layer(t, OFF_RGB, 8, 1, ID_RGB_W, 3, 128, ident);
+    for (int n = 0; n < 256; ++n)
+        for (int k = 0; k < NCOND; ++k) {
+            t[OFF_WC0 + n * NCOND + k] = nf_code(0, n, 63 + k, 171);
+            t[OFF_WC3 + n * NCOND + k] = nf_code(6, n, 63 + k, 427);
+        }
+    for (int n = 0; n < 128; ++n)
+        for (int f = 0; f < 4; ++f)
+            for (int sc = 0; sc < 2; ++sc)
+                for (int comp = 1; comp < 3; ++comp)
+                    t[OFF_WCD + n * 16 + 4 * f + 2 * sc + (comp - 1)] = nf_code(ID_DIR0_W, n, 256 + 6 * f + 3 * sc + comp, 280);
+    const int bias_ids[7] = {1, 3, 5, 7, 9, 11, ID_FEAT_B};
+    for (int l = 0; l < 7; ++l)
+        for (int n = 0; n < 256; ++n) t[OFF_BIAS + 256 * l + n] = nf_code(bias_ids[l], 0, n, 256);
+    for (int n = 0; n < 128; ++n) {
+        t[OFF_BIAS + B_D0 + n] = nf_code(ID_DIR0_B, 0, n, 128);
+        t[OFF_BIAS + B_D1 + n] = nf_code(19, 0, n, 128);
+        t[OFF_BIAS + B_D2 + n] = nf_code(21, 0, n, 128);
+    }
+    t[OFF_BIAS + B_D0 + 128] = nf_code(ID_ALPHA_B, 0, 0, 1);
+    for (int n = 0; n < 3; ++n) t[OFF_BIAS + B_RGB + n] = nf_code(ID_RGB_B, 0, n, 3);
+}
+
+__global__ void __launch_bounds__(256) k_paper_pack(NfParamPtrs ptrs, const uint32_t* __restrict__ table,
+                                                    float* __restrict__ packed, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t code = table[i];
+        const uint32_t id = code >> 24;
+        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+    }
+}
+
+// One gather table per device, uploaded on first use.
+static std::mutex g_table_mutex;
+static uint32_t* g_table_dev[64] = {nullptr};
+
+static int nf_get_table(uint32_t** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    std::lock_guard<std::mutex> lock(g_table_mutex);
+    if (!g_table_dev[dev]) {
+        std::vector<uint32_t> host;
+        nf_build_gather_table(host);
+        uint32_t* d = nullptr;
+        e = hipMalloc(&d, host.size() * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { hipFree(d); return (int)e; }
+        g_table_dev[dev] = d;
+    }
+    *out = g_table_dev[dev];
+    return 0;
+}
+
+extern "C" size_t nf_paper_packed_floats(void) { return (size_t)nfl::PACKED_FLOATS; }
+extern "C" size_t nf_paper_cond_floats(void) { return (size_t)nfl::COND_FLOATS; }
+
+// Host-side copy of the gather table (for layout tests without a GPU): code = tensor_id << 24 | offset.
+extern "C" int nf_paper_gather_table(uint32_t* out, size_t n) {
+    if (!out || n != (size_t)nfl::PACKED_FLOATS) return NF_EINVAL;
+    std::vector<uint32_t> host;
+    nf_build_gather_table(host);
+    for (size_t i = 0; i < n; ++i) out[i] = host[i];
+    return 0;
+}
+
+extern "C" int nf_paper_pack(const float* const* params, float* packed, nf_stream_t stream) {
+    if (!params || !packed) return NF_EINVAL;
+    NfParamPtrs ptrs;
+    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) {
+        if (!params[i]) return NF_EINVAL;
+        ptrs.p[i] = params[i];
+    }
+    uint32_t* table = nullptr;
+    const int rc = nf_get_table(&table);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_paper_pack, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, packed, (int)nfl::PACKED_FLOATS);
+    NF_RETURN_LAUNCH();
+}
+
+// =================================================================================================
+// condition: per-call bias table
+//   cond[L0]  = b0  + W0[:, 63:139] (expr*1/3) + W0[:, 139:171] latent          (models.py:239-242)
+//   cond[L3]  = b3  + W3[:, 63:171] [expr/3 ; latent]                             (models.py:246)
+//   cond[D0]  = bd0 + Wd0[:, 256 + 6f + 3sc + {1,2}] . {sin,cos}({near,far} 2^f)  (Quirk Q1)
+//   every other entry is the plain bias.
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_paper_condition(const float* __restrict__ packed, const float* __restrict__ expr,
+                                                         const float* __restrict__ latent, float near_z, float far_z,
+                                                         float* __restrict__ cond) {
+    using namespace nfl;
+    __shared__ float cvec[NCOND];
+    __shared__ float dvec[16];
+    const int tid = threadIdx.x;
+    if (tid < 76) cvec[tid] = nf_div(nf_mul(expr[tid], 1.0f), 3.0f);        // (expr * 1) / 3, a true division
+    else if (tid < NCOND) cvec[tid] = latent[tid - 76];
+    if (tid >= 128 && tid < 144) {
+        const int k = tid - 128, f = k >> 2, sc = (k >> 1) & 1, comp = k & 1;
+        const float a = nf_mul(comp ? far_z : near_z, exp2f((float)f));
+        dvec[k] = sc ? cosf(a) : sinf(a);
+    }
+    __syncthreads();
+    const float* bias = packed + OFF_BIAS;
+    for (int i = blockIdx.x * blockDim.x + tid; i < COND_FLOATS; i += gridDim.x * blockDim.x) {
+        float v = bias[i];
+        if (i < B_L1 || (i >= B_L3 && i < B_L4)) {
+            const int n = i < B_L1 ? i : i - B_L3;
+            const float* w = packed + (i < B_L1 ? OFF_WC0 : OFF_WC3) + n * NCOND;
+            float s = 0.0f;
+            for (int k = 0; k < NCOND; ++k) s = fmaf(w[k], cvec[k], s);
+            v += s;
+        } else if (i >= B_D0 && i < B_D0 + 128) {
+            const float* w = packed + OFF_WCD + (i - B_D0) * 16;
+            float s = 0.0f;
+            for (int k = 0; k < 16; ++k) s = fmaf(w[k], dvec[k], s);
+            v += s;
+        }
+        cond[i] = v;
+    }
+}
+
+extern "C" int nf_paper_condition(const float* packed, const float* expr76, const float* latent32, float near_z, float far_z,
+                                  float* cond, nf_stream_t stream) {
+    if (!packed || !expr76 || !latent32 || !cond) return NF_EINVAL;
+    hipLaunchKernelGGL(k_paper_condition, dim3((nfl::COND_FLOATS + 255) / 256), dim3(256), 0, nf_s(stream), packed, expr76,
+                       latent32, near_z, far_z, cond);
+    NF_RETURN_LAUNCH();
+}
+
+// =================================================================================================
+// forward
+// =================================================================================================
+// Wave-private activation slab: [16*NT points][256 features]; the 16-byte fragment (feature/4 = q) of
+// point row p is stored at float4 index p*64 + (q ^ (p & 15)): ds_read_b128 / ds_write_b128 lane
+// groups then touch 16 distinct 16-byte bank slots (conflict-free, see nf_mlp_layout.h).
+__device__ __forceinline__ int nf_act_idx4(int prow, int q) { return prow * 64 + (q ^ (prow & 15)); }
+
+template <int NT>
+struct NfMlpState {
+    f32x4 acc[NT][16];
+};
+
+template <int NT, int NO>
+__device__ __forceinline__ void nf_load_w(f32x4 (&w)[NO], const f32x4* __restrict__ src, int lane) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no) w[no] = src[no * 64 + lane];
+}
+
+template <int NT, int NO>
+__device__ __forceinline__ void nf_mma_chunk(f32x4 (&acc)[NT][16], const f32x4 (&w)[NO], const f32x4 (&b)[NT]) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                acc[t][no] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[no][r], b[t][r], acc[t][no], 0, 0, 0);
+}
+
+// K chunks whose B fragments come from registers (PE / dir slots); NCH is small and fully unrolled.
+template <int NT, int NO, int NCH>
+__device__ __forceinline__ void nf_mma_from_regs(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, const f32x4 (&breg)[NT][NCH],
+                                                 int lane) {
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        f32x4 w[NO];
+        nf_load_w<NT, NO>(w, wsec + (size_t)j * NO * 64, lane);
+        f32x4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = breg[t][j];
+        nf_mma_chunk<NT, NO>(acc, w, b);
+    }
+}
+
+// K chunks whose B fragments come from the wave's LDS slab; weights are register double-buffered one
+// chunk ahead.  nch must be even.
+template <int NT, int NO>
+__device__ __forceinline__ void nf_mma_from_lds(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch,
+                                                const f32x4* act4, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 wa[NO], wb[NO];
+    nf_load_w<NT, NO>(wa, wsec, lane);
+#pragma unroll 1
+    for (int ni = 0; ni < nch; ni += 2) {
+        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
+        f32x4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
+        nf_mma_chunk<NT, NO>(acc, wa, b);
+        if (ni + 2 < nch) nf_load_w<NT, NO>(wa, wsec + (size_t)(ni + 2) * NO * 64, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
+        nf_mma_chunk<NT, NO>(acc, wb, b);
+    }
+}
+
+template <int NT, int NO>
+__device__ __forceinline__ void nf_init_acc(f32x4 (&acc)[NT][16], const float* __restrict__ bias, int lane) {
+    const int g = lane >> 4;
+#pragma unroll
+    for (int no = 0; no < NO; ++no) {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * no + 4 * g);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][no] = b;
+    }
+}
+
+template <int NT, int NO, bool RELU>
+__device__ __forceinline__ void nf_store_act(const f32x4 (&acc)[NT][16], f32x4* act4, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = acc[t][no];
+            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+            act4[nf_act_idx4(16 * t + c, 4 * no + g)] = v;
+        }
+}
+
+// Positional encoding of one point in B-fragment order (see nfl::pe_slot_pair).
+__device__ __forceinline__ void nf_encode_point(float px, float py, float pz, int g, f32x4 (&pe)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float v[4];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int pidx = (g < 3 ? g * 8 : 24) + j * 2 + h;
+            const int freq = pidx / 3, comp = pidx - 3 * freq;
+            const float x = comp == 0 ? px : (comp == 1 ? py : pz);
+            float s, cs;
+            sincosf(nf_mul(x, (float)(1 << freq)), &s, &cs);
+            v[2 * h] = s;
+            v[2 * h + 1] = cs;
+        }
+        if (j == 3 && g == 3) { v[0] = px; v[1] = py; v[2] = pz; v[3] = 0.0f; }
+        pe[j] = (f32x4){v[0], v[1], v[2], v[3]};
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
+                const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z,
+                int64_t n_points, int S, float* __restrict__ raw) {
+    using namespace nfl;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;                       // wave-uniform; no barriers anywhere below
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
+
+    // ---- inputs: pts = ro + rd*z (T:78), PE fragments, dir fragment -----------------------------
+    f32x4 pe[NT][4];
+    f32x4 dirf[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const int64_t ray = p / S;
+        const float zz = z[p];
+        const float dx = rd[ray * 3 + 0], dy = rd[ray * 3 + 1], dz = rd[ray * 3 + 2];
+        const float px = nf_add(ro[ray * 3 + 0], nf_mul(dx, zz));
+        const float py = nf_add(ro[ray * 3 + 1], nf_mul(dy, zz));
+        const float pz = nf_add(ro[ray * 3 + 2], nf_mul(dz, zz));
+        nf_encode_point(px, py, pz, g, pe[t]);
+        float s, cs;
+        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
+        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+    }
+
+    f32x4 acc[NT][16];
+    // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    // ---- layers_xyz.1, .2 ------------------------------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_L1 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_L2 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    // ---- layers_xyz.4, .5 ------------------------------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_L4 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_L5 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    // ---- fc_feat (no activation, M:250) ------------------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
+    nf_store_act<NT, 16, false>(acc, act4, lane);
+    // ---- layers_dir.0 : [feat | dir slots] -> 128, ReLU; tile 8 row 0 = fc_alpha(feat) (Q2) ----------
+    nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
+    nf_mma_from_lds<NT, 9>(acc, W + OFF_D0 / 4, 16, act4, lane);
+    nf_mma_from_regs<NT, 9, 1>(acc, W + OFF_D0 / 4 + 16 * 9 * 64, dirf, lane);
+    float sigma_raw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
+    nf_store_act<NT, 8, true>(acc, act4, lane);
+    // ---- layers_dir.1, .2 -----------------------------------------------------------------------------
+    nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
+    nf_mma_from_lds<NT, 8>(acc, W + OFF_D1 / 4, 8, act4, lane);
+    nf_store_act<NT, 8, true>(acc, act4, lane);
+    nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
+    nf_mma_from_lds<NT, 8>(acc, W + OFF_D2 / 4, 8, act4, lane);
+    nf_store_act<NT, 8, true>(acc, act4, lane);
+    // ---- fc_rgb -------------------------------------------------------------------------------------------
+    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
+    nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t p = p0 + 16 * t + c;
+            if (p < n_points)
+                reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+        }
+    }
+}
+
+extern "C" int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    if (!packed || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
+    const int64_t n_points = n_rays * n_samples;
+    if (n_points == 0) return 0;
+    constexpr int NT = 2;
+    const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
+    const int64_t grid = (n_points + per_block - 1) / per_block;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_paper_mlp_fwd<NT>, dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro, rd,
+                       rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+    NF_RETURN_LAUNCH();
+}

@@ -1,0 +1,71 @@
+// Layout of the fragment-ordered weight image ("packed") and of the per-call bias table ("cond")
+// shared by the pack / condition / forward / backward kernels of the fused paper MLP.
+//
+// MFMA: v_mfma_f32_16x16x4_f32, D[16 out-features x 16 points] += A[16 x 4] * B[4 x 16]
+//   lane l = (g = l>>4, i = l&15):  A operand = W[n0+i][k_g],  B operand = act[point i][k_g],
+//   D regs r=0..3 = out-feature n0 + 4g + r of point i.
+// The K dimension is consumed in 16-wide chunks; inside chunk `ni`, MFMA step r (0..3) takes from lane
+// group g the K slot 16*ni + 4*g + r.  So a lane's four A (or B) values of one chunk are 4 consecutive
+// K slots = one 16-byte load, and -- because D's row index is 4g+r too -- the output registers of one
+// layer already ARE the B operands of the next layer (slot n == feature n): activations only ever move
+// as whole 16-byte fragments, never element-wise.
+//
+// A fragment block (ni, no) = 64 lanes x 4 floats = 1 KiB, contiguous; a layer section is
+// [ni][no][lane][4], so one K-chunk of a layer is NO consecutive KiB (perfectly coalesced wave loads).
+#pragma once
+
+namespace nfl {
+
+// ---- MFMA layers -------------------------------------------------------------------------------
+//                       K chunks                        N tiles
+// L0  (layers_xyz.0)    4  (PE slots)                   16
+// L1,L2,L4,L5,FEAT      16 (hidden)                     16
+// L3  (layers_xyz.3)    4 (PE) + 16 (hidden)            16
+// D0  (layers_dir.0)    16 (feat) + 1 (dir slots)       8 + 1 (tile 8, row 0 = fc_alpha)
+// D1,D2                 8                               8
+// RGB (fc_rgb)          8                               1 (rows 0..2)
+constexpr int FRAG = 256;                       // floats per (ni, no) fragment block
+constexpr int OFF_L0 = 0;
+constexpr int OFF_L1 = OFF_L0 + 4 * 16 * FRAG;
+constexpr int OFF_L2 = OFF_L1 + 16 * 16 * FRAG;
+constexpr int OFF_L3 = OFF_L2 + 16 * 16 * FRAG;
+constexpr int OFF_L4 = OFF_L3 + 20 * 16 * FRAG;
+constexpr int OFF_L5 = OFF_L4 + 16 * 16 * FRAG;
+constexpr int OFF_FEAT = OFF_L5 + 16 * 16 * FRAG;
+constexpr int OFF_D0 = OFF_FEAT + 16 * 16 * FRAG;
+constexpr int OFF_D1 = OFF_D0 + 17 * 9 * FRAG;
+constexpr int OFF_D2 = OFF_D1 + 8 * 8 * FRAG;
+constexpr int OFF_RGB = OFF_D2 + 8 * 8 * FRAG;
+constexpr int FRAG_END = OFF_RGB + 8 * 1 * FRAG;
+
+// ---- conditioning matrices (row-major) -----------------------------------------------------------
+constexpr int NCOND = 108;                      // 76 expression + 32 latent columns
+constexpr int OFF_WC0 = FRAG_END;               // [256][108] = layers_xyz.0.weight[:, 63:171]
+constexpr int OFF_WC3 = OFF_WC0 + 256 * NCOND;  // [256][108] = layers_xyz.3.weight[:, 63:171]
+constexpr int OFF_WCD = OFF_WC3 + 256 * NCOND;  // [128][16]  = layers_dir.0.weight[:, 256+6f+3sc+{1,2}], col = 4f+2sc+(comp-1)
+constexpr int OFF_BIAS = OFF_WCD + 128 * 16;    // un-folded bias table, same layout as `cond`
+// ---- bias table / cond layout ----------------------------------------------------------------------
+constexpr int B_L0 = 0, B_L1 = 256, B_L2 = 512, B_L3 = 768, B_L4 = 1024, B_L5 = 1280, B_FEAT = 1536;
+constexpr int B_D0 = 1792;                      // 128 + 16 (alpha tile: [fc_alpha.bias, 0 x 15])
+constexpr int B_D1 = B_D0 + 144, B_D2 = B_D1 + 128, B_RGB = B_D2 + 128;   // rgb tile: [b_r, b_g, b_b, 0 x 13]
+constexpr int COND_FLOATS = B_RGB + 16;         // 2208
+constexpr int PACKED_FLOATS = OFF_BIAS + COND_FLOATS;
+
+// ---- PE slot permutation ---------------------------------------------------------------------------
+// PE slot s = 16*j + 4*g + r (chunk j, lane group g, step r).  Lane groups 0..2 hold 8 (freq, comp)
+// pairs per point, as (sin, cos) register pairs, so that ONE sincosf feeds two slots; group 3 holds
+// pairs 24..29, the raw xyz (chunk 3, r = 0..2) and the zero pad (chunk 3, r = 3).
+//   pair index pidx -> freq = pidx / 3, comp = pidx % 3;  reference column = 3 + 6*freq + 3*sc + comp
+//   (reference layout [x y z | sin f0 xyz | cos f0 xyz | sin f1 xyz | ...], nerf_helpers.py:231-239).
+__host__ __device__ inline int pe_slot_pair(int j, int g, int r) {           // -1: not a sin/cos slot
+    if (g < 3) return g * 8 + j * 2 + (r >> 1);
+    return j < 3 ? 24 + j * 2 + (r >> 1) : -1;
+}
+__host__ __device__ inline int pe_slot_to_col(int slot) {                     // -1: zero pad
+    const int j = slot >> 4, g = (slot >> 2) & 3, r = slot & 3;
+    const int pidx = pe_slot_pair(j, g, r);
+    if (pidx >= 0) return 3 + 6 * (pidx / 3) + 3 * (r & 1) + (pidx % 3);
+    return r < 3 ? r : -1;
+}
+
+}  // namespace nfl

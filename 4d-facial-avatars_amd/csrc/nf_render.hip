@@ -1,0 +1,375 @@
+// K5 volume integrator (fwd + bwd), K6 inverse-CDF sampler, K7 per-ray sort, and the fused
+// hierarchical-resampling kernel (z_mid -> sample_pdf -> sort(cat)).
+//
+// Mapping: ONE 64-lane wavefront per ray, samples strided over lanes (sample s lives in lane s%64,
+// chunk s/64) so every global access of a wave is a contiguous, coalesced run.  The transmittance
+// cumprod, the CDF cumsum and the reductions are wavefront scans / butterflies on cross-lane shuffles
+// (no LDS, no block barrier); only the CDF search table and the bitonic sort use wave-private LDS.
+// These kernels are HBM-bound (K5: 20 B/sample read + 4 B/sample written).
+#include "nf_common.h"
+
+#define NF_RAYS_PER_BLOCK 4                   // 4 waves = 256 threads per block, one ray each
+#define NF_MAX_CHUNKS 16                      // <= 1024 samples per ray
+#define NF_MAX_BINS 512
+#define NF_MAX_SORT 1024
+
+__device__ __forceinline__ int nf_lane() { return threadIdx.x & 63; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_scan_add(float v) {       // inclusive
+    const int l = nf_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o, 64); if (l >= o) v += t; }
+    return v;
+}
+__device__ __forceinline__ float wave_scan_mul(float v) {       // inclusive
+    const int l = nf_lane();
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float t = __shfl_up(v, o, 64); if (l >= o) v *= t; }
+    return v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Per-sample quantities of volume_render_radiance_field (reference volume_rendering_utils.py:19-55)
+// ---------------------------------------------------------------------------------------------
+struct NfSample {
+    float c[3];     // colour entering the sum (sigmoid(raw) or the background for the last sample)
+    float alpha;    // 1 - exp(-sigma*dist)
+    float dist;
+    float pre;      // raw_sigma + noise (ReLU argument)
+    bool  is_bg;
+};
+
+__device__ __forceinline__ float nf_sigmoid(float x) { return nf_div(1.0f, nf_add(1.0f, expf(-x))); }
+
+__device__ __forceinline__ NfSample nf_load_sample(const float4* __restrict__ raw_row, const float* __restrict__ z_row,
+                                                   const float* __restrict__ noise_row, const float* __restrict__ bg_ray,
+                                                   float rd_norm, int s, int S) {
+    NfSample o;
+    const float4 r = raw_row[s];
+    const bool last = (s == S - 1);
+    o.is_bg = last && bg_ray != nullptr;
+    if (o.is_bg) { o.c[0] = bg_ray[0]; o.c[1] = bg_ray[1]; o.c[2] = bg_ray[2]; }
+    else { o.c[0] = nf_sigmoid(r.x); o.c[1] = nf_sigmoid(r.y); o.c[2] = nf_sigmoid(r.z); }
+    const float d = last ? 1e10f : nf_sub(z_row[s + 1], z_row[s]);
+    o.dist = nf_mul(d, rd_norm);
+    o.pre = noise_row ? nf_add(r.w, noise_row[s]) : r.w;
+    float sigma = fmaxf(o.pre, 0.0f);
+    if (last) sigma = nf_add(sigma, 1e-6f);                       // V:52-53
+    o.alpha = nf_sub(1.0f, expf(-nf_mul(sigma, o.dist)));
+    return o;
+}
+
+__device__ __forceinline__ float nf_rd_norm(const float* __restrict__ rd_ray) {
+    const float x = rd_ray[0], y = rd_ray[1], zc = rd_ray[2];
+    return sqrtf(nf_add(nf_add(nf_mul(x, x), nf_mul(y, y)), nf_mul(zc, zc)));
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 forward
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                           const float* __restrict__ rd, const float* __restrict__ noise,
+                                                           const float* __restrict__ bg, int64_t n_rays, int S,
+                                                           int white_bg, float* __restrict__ rgb, float* __restrict__ disp,
+                                                           float* __restrict__ acc, float* __restrict__ weights) {
+    const int lane = nf_lane();
+    const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float4* raw_row = reinterpret_cast<const float4*>(raw) + ray * S;
+    const float* z_row = z + ray * S;
+    const float* noise_row = noise ? noise + ray * S : nullptr;
+    const float* bg_ray = bg ? bg + ray * 3 : nullptr;
+    const float norm = nf_rd_norm(rd + ray * 3);
+    float carry = 1.0f;                        // running exclusive transmittance at the chunk start
+    float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_w = 0.f;
+    for (int base = 0; base < S; base += 64) {
+        const int s = base + lane;
+        const bool on = s < S;
+        float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = 0.f;
+        if (on) {
+            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S);
+            alpha = q.alpha; c0 = q.c[0]; c1 = q.c[1]; c2 = q.c[2]; zz = z_row[s];
+        }
+        const float b = on ? nf_add(nf_sub(1.0f, alpha), 1e-10f) : 1.0f;
+        const float incl = wave_scan_mul(b);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        const float T = nf_mul(carry, excl);
+        const float w = nf_mul(alpha, T);
+        if (on) weights[ray * S + s] = w;
+        a_r += w * c0; a_g += w * c1; a_b += w * c2; a_d += w * zz; a_w += w;
+        carry = nf_mul(carry, __shfl(incl, 63, 64));
+    }
+    a_r = wave_sum(a_r); a_g = wave_sum(a_g); a_b = wave_sum(a_b); a_d = wave_sum(a_d); a_w = wave_sum(a_w);
+    if (lane == 0) {
+        if (white_bg) { const float k = nf_sub(1.0f, a_w); a_r += k; a_g += k; a_b += k; }
+        rgb[ray * 3 + 0] = a_r; rgb[ray * 3 + 1] = a_g; rgb[ray * 3 + 2] = a_b;
+        acc[ray] = a_w;
+        disp[ray] = nf_div(1.0f, fmaxf(1e-10f, nf_div(a_d, a_w)));
+    }
+}
+
+extern "C" int nf_volume_render_fwd(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
+                                    int64_t n_rays, int n_samples, int white_background, float* rgb, float* disp,
+                                    float* acc, float* weights, nf_stream_t stream) {
+    if (!raw || !z || !rd || !rgb || !disp || !acc || !weights || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
+    if (n_rays == 0) return 0;
+    const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_volume_render_fwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, z, rd, noise, bg, n_rays,
+                       n_samples, white_background, rgb, disp, acc, weights);
+    NF_RETURN_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K5 backward: d_raw from d_rgb.   With b_j = 1-alpha_j+1e-10, T_i = prod_{j<i} b_j, w_i = alpha_i T_i:
+//   dL/dw_i     = <d_rgb, c_i>  (+ white-bg term: -sum(d_rgb))
+//   dL/dalpha_i = dw_i T_i - (sum_{k>i} dw_k w_k) / b_i
+//   dL/dsigma_i = dL/dalpha_i * dist_i * (1-alpha_i);   dL/dpre_i = [pre_i > 0] dL/dsigma_i
+//   dL/draw_rgb = w_i d_rgb c(1-c)   (zero for the background sample, whose colour is a constant)
+// Two passes over the ray's chunks; the forward quantities are recomputed, not stored.
+// ---------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restrict__ raw, const float* __restrict__ z,
+                                                           const float* __restrict__ rd, const float* __restrict__ noise,
+                                                           const float* __restrict__ bg, const float* __restrict__ d_rgb,
+                                                           int64_t n_rays, int S, int white_bg, float* __restrict__ d_raw) {
+    const int lane = nf_lane();
+    const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
+    if (ray >= n_rays) return;
+    const float4* raw_row = reinterpret_cast<const float4*>(raw) + ray * S;
+    const float* z_row = z + ray * S;
+    const float* noise_row = noise ? noise + ray * S : nullptr;
+    const float* bg_ray = bg ? bg + ray * 3 : nullptr;
+    const float norm = nf_rd_norm(rd + ray * 3);
+    const float g0 = d_rgb[ray * 3 + 0], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
+    const float gw_white = white_bg ? -(g0 + g1 + g2) : 0.0f;
+
+    float T[NCH], w[NCH], dw[NCH], alpha[NCH], dist[NCH], pre[NCH], c[NCH][3];
+    bool isbg[NCH];
+    float carry = 1.0f, total = 0.0f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int s = k * 64 + lane;
+        const bool on = s < S;
+        alpha[k] = 0.f; dist[k] = 0.f; pre[k] = 0.f; c[k][0] = c[k][1] = c[k][2] = 0.f; isbg[k] = false;
+        if (on) {
+            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S);
+            alpha[k] = q.alpha; dist[k] = q.dist; pre[k] = q.pre; isbg[k] = q.is_bg;
+            c[k][0] = q.c[0]; c[k][1] = q.c[1]; c[k][2] = q.c[2];
+        }
+        const float b = on ? nf_add(nf_sub(1.0f, alpha[k]), 1e-10f) : 1.0f;
+        const float incl = wave_scan_mul(b);
+        float excl = __shfl_up(incl, 1, 64);
+        if (lane == 0) excl = 1.0f;
+        T[k] = carry * excl;
+        w[k] = alpha[k] * T[k];
+        dw[k] = on ? (g0 * c[k][0] + g1 * c[k][1] + g2 * c[k][2] + gw_white) : 0.0f;
+        carry *= __shfl(incl, 63, 64);
+        total += wave_sum(dw[k] * w[k]);
+    }
+    float prefix = 0.0f;                       // sum over all earlier chunks of dw*w
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int s = k * 64 + lane;
+        const float v = dw[k] * w[k];
+        const float incl = wave_scan_add(v);
+        const float suffix = total - (prefix + incl);      // sum_{j>s} dw_j w_j
+        prefix += __shfl(incl, 63, 64);
+        if (s < S) {
+            const float b = (1.0f - alpha[k]) + 1e-10f;
+            const float d_alpha = dw[k] * T[k] - suffix / b;
+            const float d_sigma = d_alpha * dist[k] * (1.0f - alpha[k]);
+            float4 o;
+            if (isbg[k]) { o.x = o.y = o.z = 0.0f; }
+            else {
+                o.x = w[k] * g0 * c[k][0] * (1.0f - c[k][0]);
+                o.y = w[k] * g1 * c[k][1] * (1.0f - c[k][1]);
+                o.z = w[k] * g2 * c[k][2] * (1.0f - c[k][2]);
+            }
+            o.w = pre[k] > 0.0f ? d_sigma : 0.0f;
+            reinterpret_cast<float4*>(d_raw)[ray * S + s] = o;
+        }
+    }
+}
+
+extern "C" int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
+                                    const float* d_rgb, int64_t n_rays, int n_samples, int white_background, float* d_raw,
+                                    nf_stream_t stream) {
+    if (!raw || !z || !rd || !d_rgb || !d_raw || n_rays < 0 || n_samples <= 0 || n_samples > 64 * NF_MAX_CHUNKS) return NF_EINVAL;
+    if (n_rays == 0) return 0;
+    const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    const int nch = (n_samples + 63) / 64;
+#define NF_BWD(N)                                                                                                         \
+    hipLaunchKernelGGL(k_volume_render_bwd<N>, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, z, rd, noise, bg,   \
+                       d_rgb, n_rays, n_samples, white_background, d_raw)
+    if (nch == 1) NF_BWD(1); else if (nch == 2) NF_BWD(2); else if (nch == 3) NF_BWD(3); else if (nch == 4) NF_BWD(4);
+    else if (nch <= 8) NF_BWD(8); else NF_BWD(16);
+#undef NF_BWD
+    NF_RETURN_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6: sample_pdf_2 (reference nerf_helpers.py:344-387), wave-private LDS tables.
+//   cdf[0] = 0, cdf[i] = cumsum((w+1e-5)/sum(w+1e-5))[i-1];  idx = #{cdf <= u} (searchsorted right=True)
+// `lds_cdf`/`lds_bins` are this wave's tables (n_bins entries each); returns via callback-free loop.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nf_build_cdf(const float* __restrict__ w_row, int n_w, float* lds_cdf) {
+    const int lane = nf_lane();
+    float part = 0.0f;
+    for (int i = lane; i < n_w; i += 64) part += nf_add(w_row[i], 1e-5f);
+    const float sum = wave_sum(part);
+    float carry = 0.0f;
+    if (lane == 0) lds_cdf[0] = 0.0f;
+    for (int base = 0; base < n_w; base += 64) {
+        const int i = base + lane;
+        const float pdf = i < n_w ? nf_div(nf_add(w_row[i], 1e-5f), sum) : 0.0f;
+        const float incl = wave_scan_add(pdf);
+        if (i < n_w) lds_cdf[i + 1] = carry + incl;
+        carry += __shfl(incl, 63, 64);
+    }
+}
+
+__device__ __forceinline__ float nf_invert_cdf(const float* lds_cdf, const float* lds_bins, int n_bins, float u) {
+    int lo = 0, hi = n_bins;                   // first index with cdf > u  (== count of cdf <= u)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (lds_cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+    const int below = lo - 1 > 0 ? lo - 1 : 0;
+    const int above = lo < n_bins - 1 ? lo : n_bins - 1;
+    const float cb = lds_cdf[below], ca = lds_cdf[above];
+    const float bb = lds_bins[below], ba = lds_bins[above];
+    float den = nf_sub(ca, cb);
+    if (den < 1e-5f) den = 1.0f;
+    const float t = nf_div(nf_sub(u, cb), den);
+    return nf_add(bb, nf_mul(t, nf_sub(ba, bb)));
+}
+
+__global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights,
+                                                    const float* __restrict__ u, int64_t u_stride, int64_t n_rays,
+                                                    int n_bins, int n_out, float* __restrict__ samples) {
+    __shared__ float lds[NF_RAYS_PER_BLOCK][2 * NF_MAX_BINS];
+    const int lane = nf_lane(), wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
+    float* cdf = lds[wv];
+    float* lb = lds[wv] + NF_MAX_BINS;
+    if (ray < n_rays) {
+        nf_build_cdf(weights + ray * (n_bins - 1), n_bins - 1, cdf);
+        for (int i = lane; i < n_bins; i += 64) lb[i] = bins[ray * n_bins + i];
+    }
+    __syncthreads();
+    if (ray < n_rays)
+        for (int j = lane; j < n_out; j += 64)
+            samples[ray * n_out + j] = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j]);
+}
+
+extern "C" int nf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
+                             int n_bins, int n_out, float* samples, nf_stream_t stream) {
+    if (!bins || !weights || !u || !samples || n_rays < 0 || n_bins < 2 || n_bins > NF_MAX_BINS || n_out <= 0) return NF_EINVAL;
+    if (n_rays == 0) return 0;
+    const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), bins, weights, u, u_row_stride, n_rays,
+                       n_bins, n_out, samples);
+    NF_RETURN_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7: ascending bitonic sort of one row per wave in wave-private LDS (n padded to a power of two
+// with +inf).  Values only (the reference discards torch.sort's indices, T:126).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nf_bitonic_sort(float* buf, int n_pow2) {
+    const int lane = nf_lane();
+    for (int k = 2; k <= n_pow2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = lane; t < (n_pow2 >> 1); t += 64) {
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));   // lower index of the pair
+                const int p = i | j;
+                const bool up = (i & k) == 0;
+                const float a = buf[i], b = buf[p];
+                if ((a > b) == up) { buf[i] = b; buf[p] = a; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__device__ __forceinline__ int nf_next_pow2(int n) { int p = 2; while (p < n) p <<= 1; return p; }
+
+__global__ void __launch_bounds__(256) k_sort_rows(const float* __restrict__ in, int64_t n_rows, int n_cols,
+                                                   float* __restrict__ out) {
+    __shared__ float lds[NF_RAYS_PER_BLOCK][NF_MAX_SORT];
+    const int lane = nf_lane(), wv = threadIdx.x >> 6;
+    const int64_t row = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
+    const bool on = row < n_rows;
+    const int np2 = nf_next_pow2(n_cols);
+    for (int i = lane; i < np2; i += 64) lds[wv][i] = (on && i < n_cols) ? in[row * n_cols + i] : INFINITY;
+    __syncthreads();
+    nf_bitonic_sort(lds[wv], np2);
+    if (on) for (int i = lane; i < n_cols; i += 64) out[row * n_cols + i] = lds[wv][i];
+}
+
+extern "C" int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream) {
+    if (!in || !out || n_rows < 0 || n_cols <= 0 || n_cols > NF_MAX_SORT) return NF_EINVAL;
+    if (n_rows == 0) return 0;
+    const int64_t grid = (n_rows + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), in, n_rows, n_cols, out);
+    NF_RETURN_LAUNCH();
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6+K7 fused (reference train_utils.py:116-126): bins = 0.5*(z[1:]+z[:-1]), weights = w[1:-1],
+// z_samples = sample_pdf(...), z_fine = sort(cat(z, z_samples)).  One wave per ray; everything stays
+// in wave-private LDS between the stages: HBM traffic is 8*Nc read + 4*(Nc+Nf) (+4*Nf) written per ray.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict__ zc, const float* __restrict__ wc,
+                                                        const float* __restrict__ u, int64_t u_stride, int64_t n_rays,
+                                                        int nc, int nf, float* __restrict__ z_samples,
+                                                        float* __restrict__ z_fine) {
+    __shared__ float lds[NF_RAYS_PER_BLOCK][2 * NF_MAX_BINS + NF_MAX_SORT];
+    const int lane = nf_lane(), wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
+    const bool on = ray < n_rays;
+    float* cdf = lds[wv];
+    float* lb = lds[wv] + NF_MAX_BINS;
+    float* srt = lds[wv] + 2 * NF_MAX_BINS;
+    const int n_bins = nc - 1, nt = nc + nf, np2 = nf_next_pow2(nt);
+    if (on) {
+        nf_build_cdf(wc + ray * nc + 1, nc - 2, cdf);
+        for (int i = lane; i < nc; i += 64) {
+            const float zi = zc[ray * nc + i];
+            srt[i] = zi;
+            if (i < n_bins) lb[i] = nf_mul(0.5f, nf_add(zc[ray * nc + i + 1], zi));
+        }
+    }
+    for (int i = nt + lane; i < np2; i += 64) srt[i] = INFINITY;
+    __syncthreads();
+    if (on)
+        for (int j = lane; j < nf; j += 64) {
+            const float v = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j]);
+            srt[nc + j] = v;
+            if (z_samples) z_samples[ray * nf + j] = v;
+        }
+    __syncthreads();
+    nf_bitonic_sort(srt, np2);
+    if (on) for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = srt[i];
+}
+
+extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
+                                 int64_t n_rays, int n_coarse, int n_fine, float* z_samples, float* z_fine,
+                                 nf_stream_t stream) {
+    if (!z_coarse || !w_coarse || !u || !z_fine || n_rays < 0 || n_coarse < 3 || n_coarse - 1 > NF_MAX_BINS || n_fine <= 0 ||
+        n_coarse + n_fine > NF_MAX_SORT)
+        return NF_EINVAL;
+    if (n_rays == 0) return 0;
+    const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_resample_merge, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), z_coarse, w_coarse, u, u_row_stride,
+                       n_rays, n_coarse, n_fine, z_samples, z_fine);
+    NF_RETURN_LAUNCH();
+}

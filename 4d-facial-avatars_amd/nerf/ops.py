@@ -1,0 +1,221 @@
+"""Tensor-level wrappers over the C ABI (one function per entry point of include/nerface_hip.h).
+
+These allocate outputs with torch, pass raw device pointers + the current HIP stream, and translate
+non-zero return codes into RuntimeError.  No numerical work happens in Python.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import weakref
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _hip as H
+
+PAPER_KEYS = (
+    [f"layers_xyz.{i}.{p}" for i in range(6) for p in ("weight", "bias")]
+    + [f"{n}.{p}" for n in ("fc_feat", "fc_alpha") for p in ("weight", "bias")]
+    + [f"layers_dir.{i}.{p}" for i in range(4) for p in ("weight", "bias")]
+    + [f"fc_rgb.{p}" for p in ("weight", "bias")]
+)
+
+
+def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------- tables
+_LINSPACE_CACHE = {}
+
+
+def linspace01(n: int, device) -> torch.Tensor:
+    """torch.linspace(0, 1, n) as the reference calls it (T:50-55, H:357-360).  The table is produced by
+    torch's own CPU kernel once per (n, device) and cached on the device, so that the deterministic
+    depths / CDF abscissae carry exactly torch's rounding."""
+    key = (int(n), str(device))
+    t = _LINSPACE_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, int(n), dtype=torch.float32).to(device)
+        _LINSPACE_CACHE[key] = t
+    return t
+
+
+# ---------------------------------------------------------------------------------------- K1
+def ray_bundle(height: int, width: int, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor):
+    c2w = c2w if (c2w.dtype == torch.float32 and c2w.stride(-1) == 1) else c2w.to(torch.float32).contiguous()
+    if not c2w.is_cuda:
+        raise RuntimeError("get_ray_bundle (MI355X build): tform_cam2world must be on a ROCm device")
+    if c2w.dim() != 2 or c2w.shape[0] < 3 or c2w.shape[1] < 4:
+        raise ValueError("tform_cam2world must be (3|4, 4)")
+    dev = c2w.device
+    ro = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((height, width, 3), dtype=torch.float32, device=dev)
+    # W*cx and H*cy are formed in double and rounded once, as python-scalar operands are in the reference
+    cx_w = float(np.float32(np.float64(width) * np.float64(cx)))
+    cy_h = float(np.float32(np.float64(height) * np.float64(cy)))
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_ray_bundle(height, width, float(np.float32(fx)), float(np.float32(fy)), cx_w, cy_h,
+                                      H.ptr(c2w), int(c2w.stride(0)), H.ptr(ro), H.ptr(rd), H.stream_ptr(dev)),
+                "nf_ray_bundle")
+    return ro, rd
+
+
+# ---------------------------------------------------------------------------------------- K2
+def sample_coarse(n_rays: int, n_coarse: int, near: float, far: float, device, t_rand: Optional[torch.Tensor] = None):
+    t_rand = _c(t_rand)
+    tv = linspace01(n_coarse, device)
+    z = torch.empty((n_rays, n_coarse), dtype=torch.float32, device=device)
+    if t_rand is not None:
+        H.require_device(t_rand)
+        assert tuple(t_rand.shape) == (n_rays, n_coarse)
+    with torch.cuda.device(device):
+        H.check(H.lib().nf_sample_coarse(n_rays, n_coarse, float(np.float32(near)), float(np.float32(far)), H.ptr(tv),
+                                         H.ptr(t_rand), H.ptr(z), H.stream_ptr(device)), "nf_sample_coarse")
+    return z
+
+
+# ---------------------------------------------------------------------------------------- K3
+def posenc(x: torch.Tensor, n_freq: int, include_input: bool) -> torch.Tensor:
+    x = _c(x)
+    dev = H.require_device(x)
+    dim = x.shape[-1]
+    rows = x.numel() // dim if dim else 0
+    width = dim * ((1 if include_input else 0) + 2 * n_freq)
+    out = torch.empty(tuple(x.shape[:-1]) + (width,), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_posenc(H.ptr(x), rows, dim, n_freq, 1 if include_input else 0, H.ptr(out), H.stream_ptr(dev)),
+                "nf_posenc")
+    return out
+
+
+# ---------------------------------------------------------------------------------------- K4
+class PaperWeights:
+    """Fragment-ordered weight image of one ConditionalBlendshapePaperNeRFModel on one device, re-packed
+    whenever a parameter's version counter moves (i.e. after optimizer.step() / load_state_dict())."""
+
+    def __init__(self, params: Sequence[torch.Tensor]):
+        assert len(params) == H.NF_PAPER_NUM_PARAMS
+        self._params = list(params)
+        self._versions = None
+        self._ptrs = None
+        self.packed = None
+        self.packed_t = None            # transposed image for the backward chain (lazily built)
+        self._versions_t = None
+
+    def _signature(self):
+        return tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
+
+    def get(self) -> torch.Tensor:
+        sig = self._signature()
+        if self.packed is None or sig != self._versions:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed is None or self.packed.device != dev:
+                self.packed = torch.empty(lib.nf_paper_packed_floats(), dtype=torch.float32, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack(arr, H.ptr(self.packed), H.stream_ptr(dev)), "nf_paper_pack")
+            self._versions = sig
+        return self.packed
+
+
+def paper_condition(packed: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor, near: float, far: float) -> torch.Tensor:
+    expr, latent = _c(expr.detach()), _c(latent.detach())
+    dev = H.require_device(packed, expr, latent)
+    if expr.numel() != 76 or latent.numel() != 32:
+        raise ValueError("expected a 76-d expression and a 32-d latent code")
+    lib = H.lib()
+    cond = torch.empty(lib.nf_paper_cond_floats(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(lib.nf_paper_condition(H.ptr(packed), H.ptr(expr), H.ptr(latent), float(np.float32(near)),
+                                       float(np.float32(far)), H.ptr(cond), H.stream_ptr(dev)), "nf_paper_condition")
+    return cond
+
+
+def paper_mlp_fwd(packed, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
+    dev = H.require_device(packed, cond, ro, rd, z, rd_view)
+    n_rays, n_samples = z.shape
+    raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_paper_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                         n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd")
+    return raw
+
+
+# ---------------------------------------------------------------------------------------- K5
+def volume_render_fwd(raw, z, rd, noise=None, bg=None, white_background=False):
+    dev = H.require_device(raw, z, rd, noise, bg)
+    n_rays, n_samples = z.shape
+    rgb = torch.empty((n_rays, 3), dtype=torch.float32, device=dev)
+    disp = torch.empty((n_rays,), dtype=torch.float32, device=dev)
+    acc = torch.empty((n_rays,), dtype=torch.float32, device=dev)
+    w = torch.empty((n_rays, n_samples), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_volume_render_fwd(H.ptr(raw), H.ptr(z), H.ptr(rd), H.ptr(noise), H.ptr(bg), n_rays, n_samples,
+                                             1 if white_background else 0, H.ptr(rgb), H.ptr(disp), H.ptr(acc), H.ptr(w),
+                                             H.stream_ptr(dev)), "nf_volume_render_fwd")
+    return rgb, disp, acc, w
+
+
+def volume_render_bwd(raw, z, rd, noise, bg, d_rgb, white_background=False):
+    d_rgb = _c(d_rgb)
+    dev = H.require_device(raw, z, rd, noise, bg, d_rgb)
+    n_rays, n_samples = z.shape
+    d_raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_volume_render_bwd(H.ptr(raw), H.ptr(z), H.ptr(rd), H.ptr(noise), H.ptr(bg), H.ptr(d_rgb), n_rays,
+                                             n_samples, 1 if white_background else 0, H.ptr(d_raw), H.stream_ptr(dev)),
+                "nf_volume_render_bwd")
+    return d_raw
+
+
+# ---------------------------------------------------------------------------------------- K6 / K7
+def _u_arg(u: Optional[torch.Tensor], n_rays: int, n_out: int, device):
+    if u is None:                                     # det mode (H:357-362): linspace(0,1,n) broadcast over rays
+        return linspace01(n_out, device), 0
+    u = _c(u)
+    H.require_device(u)
+    assert tuple(u.shape) == (n_rays, n_out), (tuple(u.shape), (n_rays, n_out))
+    return u, n_out
+
+
+def sample_pdf(bins, weights, n_out: int, u: Optional[torch.Tensor] = None):
+    bins, weights = _c(bins), _c(weights)
+    dev = H.require_device(bins, weights)
+    n_rays, n_bins = bins.shape
+    assert weights.shape == (n_rays, n_bins - 1)
+    u_t, stride = _u_arg(u, n_rays, n_out, dev)
+    out = torch.empty((n_rays, n_out), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_sample_pdf(H.ptr(bins), H.ptr(weights), H.ptr(u_t), stride, n_rays, n_bins, n_out, H.ptr(out),
+                                      H.stream_ptr(dev)), "nf_sample_pdf")
+    return out
+
+
+def resample_merge(z_coarse, w_coarse, n_fine: int, u: Optional[torch.Tensor] = None, want_samples: bool = False):
+    dev = H.require_device(z_coarse, w_coarse)
+    n_rays, n_coarse = z_coarse.shape
+    u_t, stride = _u_arg(u, n_rays, n_fine, dev)
+    z_fine = torch.empty((n_rays, n_coarse + n_fine), dtype=torch.float32, device=dev)
+    z_s = torch.empty((n_rays, n_fine), dtype=torch.float32, device=dev) if want_samples else None
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_resample_merge(H.ptr(z_coarse), H.ptr(w_coarse), H.ptr(u_t), stride, n_rays, n_coarse, n_fine,
+                                          H.ptr(z_s), H.ptr(z_fine), H.stream_ptr(dev)), "nf_resample_merge")
+    return (z_fine, z_s) if want_samples else z_fine
+
+
+def sort_rows(x: torch.Tensor) -> torch.Tensor:
+    x = _c(x)
+    dev = H.require_device(x)
+    n_cols = x.shape[-1]
+    rows = x.numel() // n_cols
+    out = torch.empty_like(x)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_sort_rows(H.ptr(x), rows, n_cols, H.ptr(out), H.stream_ptr(dev)), "nf_sort_rows")
+    return out

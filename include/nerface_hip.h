@@ -1,0 +1,104 @@
+/*
+ * libnerface_hip.so -- C ABI of the MI355X (gfx950) implementation of NeRFace's ray-marching hot path.
+ *
+ * The reference (gafniguy/4D-Facial-Avatars) has no native/FFI layer: its boundary is the Python module
+ * `nerf` (nerf/__init__.py:1-9).  Each entry point below replaces the stock-PyTorch op sequence of one
+ * reference function; citations are relative to nerface_code/nerf-pytorch/ in the reference tree:
+ *   H = nerf/nerf_helpers.py  V = nerf/volume_rendering_utils.py  T = nerf/train_utils.py  M = nerf/models.py
+ *
+ * Conventions: every pointer is a DEVICE pointer to contiguous row-major fp32 unless stated otherwise;
+ * `stream` is a hipStream_t (NULL = default stream); kernels are enqueued asynchronously; the return
+ * value is 0 on success or the hipError_t of the failed launch (nf_error_string() renders it), and
+ * NF_EINVAL (-22) for an argument the library rejects.  No entry point allocates, frees or synchronises,
+ * except nf_paper_pack's one-time upload of its (static) gather table.
+ */
+#ifndef NERFACE_HIP_H
+#define NERFACE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nf_stream_t; /* hipStream_t */
+
+#define NF_EINVAL (-22)
+
+/* ---- library ------------------------------------------------------------------------------------ */
+int         nf_abi_version(void);            /* bumped on any signature change                        */
+const char* nf_error_string(int code);
+const char* nf_build_info(void);             /* "gfx950 <compiler> <date>"                            */
+
+/* ---- K1: ray generation  -- replaces get_ray_bundle (H:68-123, meshgrid_xy H:29-41) --------------- */
+/* c2w: 3 rows x >=4 floats with row stride `c2w_row_stride`; cx_w = float(W*cx), cy_h = float(H*cy)
+ * computed by the caller in double (H:111-114).  ro, rd: (H, W, 3).  Bit-exact with the reference.   */
+int nf_ray_bundle(int height, int width, float fx, float fy, float cx_w, float cy_h,
+                  const float* c2w, int c2w_row_stride, float* ro, float* rd, nf_stream_t stream);
+
+/* ---- K2: stratified coarse depths -- replaces T:56-76 -------------------------------------------- */
+/* z: (n_rays, n_coarse).  t_vals: (n_coarse) = the caller's torch.linspace(0,1,n_coarse) table (T:50-55;
+ * passing the table keeps torch's own linspace rounding).  t_rand NULL => perturb off.  Bit-exact.    */
+int nf_sample_coarse(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
+                     const float* t_rand, float* z, nf_stream_t stream);
+
+/* ---- K3: positional encoder -- replaces positional_encoding (H:195-239) --------------------------- */
+/* x: (n_rows, dim) -> out: (n_rows, dim*(include_input + 2*n_freq)), layout [x | sin f0 | cos f0 | ..] */
+int nf_posenc(const float* x, int64_t n_rows, int dim, int n_freq, int include_input, float* out,
+              nf_stream_t stream);
+
+/* ---- K4: fused MLP -- replaces run_network (T:9-33) + ConditionalBlendshapePaperNeRFModel.forward
+ *      (M:236-261) including pts = ro + rd*z (T:78), both positional encodings and all concats ------ */
+#define NF_PAPER_NUM_PARAMS 26   /* state_dict order: layers_xyz.{0..5}.{weight,bias}, fc_feat.*, fc_alpha.*,
+                                    layers_dir.{0..3}.*, fc_rgb.*   (layers_dir.3 is dead weight, Q3)  */
+size_t nf_paper_packed_floats(void);      /* size of the MFMA-fragment-ordered weight image           */
+size_t nf_paper_cond_floats(void);        /* size of the per-call bias table                          */
+/* Gather the 26 live nn.Parameter storages into the fragment-ordered image (re-run after each
+ * optimizer step).  `params` is a HOST array of 26 device pointers.                                   */
+int nf_paper_pack(const float* const* params, float* packed, nf_stream_t stream);
+/* HOST copy of the gather table behind nf_paper_pack (layout tests without a GPU):
+ * out[i] = (state_dict index << 24) | flat element offset, 0xFF000000 = constant zero.                 */
+int nf_paper_gather_table(uint32_t* out, size_t n /* must equal nf_paper_packed_floats() */);
+/* Fold the per-call constant input columns into bias vectors: expr*1/3 (76) and latent (32) into
+ * layers_xyz.0 / layers_xyz.3 (M:239-246), PE4(near), PE4(far) into layers_dir.0 (Quirk Q1, T:14).    */
+int nf_paper_condition(const float* packed, const float* expr76, const float* latent32,
+                       float near_z, float far_z, float* cond, nf_stream_t stream);
+/* raw[(ray*S + s)*4 + {0,1,2,3}] = (rgb_raw, sigma_raw) for points ro + rd*z[ray, s].                 */
+/* rd_view: per-ray vector whose z component feeds the "direction" encoding (T:14); NULL = rd.  It differs
+ * from rd only on the reference's ray-direction ablation path (T:81-82, Quirk Q7).                     */
+int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd,
+                     const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                     nf_stream_t stream);
+
+/* ---- K5: volume integrator -- replaces volume_render_radiance_field (V:7-75) + cumprod_exclusive
+ *      (H:44-65) + the background overwrite of T:95-96 ----------------------------------------------- */
+/* bg (n_rays,3) or NULL; noise (n_rays,S) already scaled by noise_std, or NULL.  Outputs: rgb (R,3),
+ * disp (R), acc (R), weights (R,S).                                                                   */
+int nf_volume_render_fwd(const float* raw, const float* z, const float* rd, const float* noise,
+                         const float* bg, int64_t n_rays, int n_samples, int white_background,
+                         float* rgb, float* disp, float* acc, float* weights, nf_stream_t stream);
+/* d_raw (R,S,4) from d_rgb (R,3) (the trainer's loss only reaches rgb_map, TR:355-387).               */
+int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, const float* noise,
+                         const float* bg, const float* d_rgb, int64_t n_rays, int n_samples,
+                         int white_background, float* d_raw, nf_stream_t stream);
+
+/* ---- K6: inverse-CDF sampler -- replaces sample_pdf_2 (H:344-387) --------------------------------- */
+/* bins (R,n_bins), weights (R,n_bins-1); u: row r at u + r*u_row_stride, n_out values
+ * (u_row_stride = n_out for torch.rand draws, 0 to broadcast the det-mode linspace(0,1,n_out) table). */
+int nf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
+                  int64_t n_rays, int n_bins, int n_out, float* samples, nf_stream_t stream);
+
+/* ---- K6+K7 fused: hierarchical resampling -- replaces T:116-126 (z_mid, sample_pdf on w[1:-1],
+ *      sort(cat(z, z_samples))) ---------------------------------------------------------------------- */
+int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
+                      int64_t n_rays, int n_coarse, int n_fine, float* z_samples /* (R,n_fine) or NULL */,
+                      float* z_fine /* (R,n_coarse+n_fine) */, nf_stream_t stream);
+
+/* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
+int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NERFACE_HIP_H */
