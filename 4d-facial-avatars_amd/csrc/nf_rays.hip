@@ -104,8 +104,8 @@ __global__ void __launch_bounds__(256) k_posenc(const float* __restrict__ x, int
 
 extern "C" int nf_posenc(const float* x, int64_t n_rows, int dim, int n_freq, int include_input, float* out,
                          nf_stream_t stream) {
-    if (!x || !out || n_rows < 0 || dim <= 0 || n_freq < 0 || n_freq > 30) return NF_EINVAL;
     if (n_rows == 0) return 0;
+    if (!x || !out || n_rows < 0 || dim <= 0 || n_freq < 0 || n_freq > 30) return NF_EINVAL;
     const int64_t total = n_rows * dim * ((include_input ? 1 : 0) + 2 * n_freq);
     if (total == 0) return 0;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);

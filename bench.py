@@ -1,0 +1,224 @@
+#!/usr/bin/env python
+"""Benchmark of the NeRFace ray-marching hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+One *step* = one full 512x512 frame through the product path exactly as eval_transformed_rays.py drives it:
+`get_ray_bundle` + `run_one_iter_of_nerf(mode="validation")` with the shipped validation settings
+(64 coarse + 128 fine samples, chunksize 65536, perturb: True, noise 0; paper model x2, expression + latent
+conditioning, background prior).  Inputs (pose, expression, latent code, background, weights) are resident in
+HBM before the timed region.  Metric (BASELINE.json): rays/sec = frames * 262144 / wall time, whole job.
+
+N > 1: frames are sharded over ranks (eval is embarrassingly parallel); no data-path
+collective; each rank renders K frames of its own (weak scaling); time = max over ranks.
+
+Also reported on the same JSON line:
+  roofline     -- the dominant kernel (fused MLP forward, fine pass: 65536 rays x 192 samples per launch), timed
+                  live with HIP events on the launch stream; achieved = algorithmic FLOPs (1,100,032 per point,
+                  SURVEY §8(d)) / average launch duration, against the dense fp32-MFMA peak (157.3 TFLOP/s).
+  cpu_baseline -- the CPU oracle (port of the reference algorithm, oracle/nerface_oracle.py) timed on this
+                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "4d-facial-avatars_amd")
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+H = W = 512
+N_COARSE, N_FINE = 64, 128
+CHUNK = 65536
+FLOP_PER_POINT = 1_100_032            # algorithmic forward FLOPs of the paper MLP per point
+PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
+INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
+NEAR, FAR = 0.2, 0.8
+
+
+def synth_params(seed, device):
+    """Random-init weights of the paper architecture (torch default nn.Linear init) with a density boost so
+    that rays are neither all-empty nor all-opaque."""
+    import nerf
+    torch.manual_seed(seed)
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False, use_viewdirs=True, num_layers=4,
+                                                        hidden_size=256, include_expression=True)
+    with torch.no_grad():
+        m.fc_alpha.weight.mul_(1000.0)
+        m.fc_alpha.bias.fill_(5.0)
+        m.fc_rgb.weight.mul_(10.0)
+    return m.to(device).eval()
+
+
+def frame_pose(f):
+    import math
+    a = 0.3 * math.sin(2 * math.pi * f / 100.0)
+    b = 0.15 * math.cos(2 * math.pi * f / 100.0)
+    ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    m = np.eye(4)
+    m[:3, :3] = ry @ rx
+    m[:3, 3] = [0.02 * math.sin(2 * math.pi * f / 100.0), 0.02 * math.cos(2 * math.pi * f / 100.0), 0.5]
+    return torch.tensor(m, dtype=torch.float32)
+
+
+def options(nerf):
+    mode = dict(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=CHUNK, perturb=True, lindisp=False,
+                radiance_field_noise_std=0.0, white_background=False)
+    return nerf.CfgNode(dict(nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode)),
+                             dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
+
+
+def cpu_baseline(n_rays=1536):
+    """Oracle (CPU port of the reference path) on a bounded sample: n_rays rays of one 512^2 frame, 64+128."""
+    from oracle import cases as C
+    from oracle import nerface_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    c = C.build_case("eval_det_64_128")
+    ro, rd, bg, _, _ = C.ray_subset(H, W, 3, n_rays, seed=5)
+    c.update(ro=ro, rd=rd, bg=bg)
+    warm = dict(c)
+    warm.update(ro=ro[:256], rd=rd[:256], bg=bg[:256])
+    with torch.no_grad():
+        C.run_oracle(warm)
+        t0 = time.perf_counter()
+        C.run_oracle(c)
+        dt = time.perf_counter() - t0
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rays", type=int, default=1536)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import __graft_entry__ as G
+    if rank == 0:
+        G._load_build().build(force=False, verbose=False)
+    if dist is not None:
+        dist.barrier()
+    import nerf
+    from nerf import ops
+
+    model_c, model_f = synth_params(0, dev), synth_params(1, dev)
+    opt = options(nerf)
+    enc_xyz = nerf.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = nerf.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    g = torch.Generator().manual_seed(7)
+    background = torch.rand((H, W, 3), generator=g).to(dev).view(-1, 3)
+    n_frames = args.steps + args.warmup
+    frames = [rank + world * i for i in range(n_frames)]                  # frame-parallel shard: f = rank (mod world)
+    poses = [frame_pose(f).to(dev) for f in frames]
+    conds = []
+    for f in frames:
+        gg = torch.Generator().manual_seed(1000 + f)
+        conds.append(((0.5 * torch.randn(76, generator=gg)).to(dev), (0.1 * torch.randn(32, generator=gg)).to(dev)))
+    torch.manual_seed(1234 + rank)
+
+    def step(i):
+        with torch.no_grad():
+            ro, rd = nerf.get_ray_bundle(H, W, INTRINSICS, poses[i])
+            return nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro, rd, opt, mode="validation",
+                                             encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                             expressions=conds[i][0], background_prior=background, latent_code=conds[i][1])
+
+    for i in range(args.warmup):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_frames):
+        out = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
+
+    rays_total = world * args.steps * H * W
+    line = {
+        "metric": "rays/sec at 512x512, 64 coarse + 128 fine samples", "value": rays_total / dt, "unit": "rays/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: paper-model eval forward, 512x512 frame, 64+128 samples, chunksize 65536, "
+                               "perturb on, expression+latent conditioned, background prior; frames sharded over GPUs",
+                   "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: fused MLP forward, fine pass of one ray chunk ----------------
+        S = N_COARSE + N_FINE
+        pk = model_f.hip_weights().get()
+        cond = ops.paper_condition(pk, conds[0][0], conds[0][1], NEAR, FAR)
+        ro, rd = nerf.get_ray_bundle(H, W, INTRINSICS, poses[0])
+        ro, rd = ro.view(-1, 3)[:CHUNK].contiguous(), rd.view(-1, 3)[:CHUNK].contiguous()
+        z = torch.sort(torch.rand((CHUNK, S), device=dev) * (FAR - NEAR) + NEAR, dim=-1)[0].contiguous()
+        for _ in range(2):
+            ops.paper_mlp_fwd(pk, cond, ro, rd, z)
+        n_launch = 8
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]   # recorded on the launch stream
+        ev[0].record()
+        for k in range(n_launch):
+            ops.paper_mlp_fwd(pk, cond, ro, rd, z)
+            ev[k + 1].record()
+        torch.cuda.synchronize()
+        avg_ms = sum(ev[k].elapsed_time(ev[k + 1]) for k in range(n_launch)) / n_launch
+        flops = float(CHUNK) * S * FLOP_PER_POINT
+        achieved = flops / (avg_ms * 1e-3) / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "mlp_fwd_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line["roofline"] = {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2> (65536 rays x 192 samples per launch)",
+                            "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": avg_ms,
+                            "algorithmic_flops_per_launch": flops, "traffic": traffic}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
