@@ -1,0 +1,128 @@
+"""CPU: the C-ABI library loads and exports every symbol include/nerface_hip.h declares; host-side logic."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "nerface_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(nf_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 17
+    for name in sorted(declared):
+        assert hasattr(hip_lib, name), f"libnerface_hip.so does not export {name}"
+    assert hip_lib.nf_abi_version() >= 1
+    assert b"gfx950" in hip_lib.nf_build_info()
+    assert hip_lib.nf_error_string(-22).startswith(b"nerface_hip")
+
+
+def test_gather_table_covers_every_live_weight_once(hip_lib):
+    """Every live weight element must appear exactly once among the MFMA fragment sections (the conditioning
+    matrices and the bias table re-reference some), and nothing may reference the dead layers_dir.3."""
+    from nerf import ops
+    n = hip_lib.nf_paper_packed_floats()
+    tab = np.zeros(n, dtype=np.uint32)
+    assert hip_lib.nf_paper_gather_table(tab.ctypes.data_as(ctypes.c_void_p), n) == 0
+    ids, offs = tab >> 24, tab & 0xFFFFFF
+    import nerf
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False)
+    shapes = [tuple(p.shape) for p in m.hip_param_list()]
+    assert len(shapes) == 26 and list(dict(m.named_parameters())) == ops.PAPER_KEYS
+    frag_end = 499968                                   # nfl::FRAG_END
+    assert not np.any((ids == 22) | (ids == 23))        # layers_dir.3.{weight,bias} (Quirk Q3)
+    for tid, shp in enumerate(shapes):
+        if tid in (22, 23):
+            continue
+        numel = int(np.prod(shp))
+        sel = offs[(ids == tid)]
+        assert sel.max() < numel
+        if len(shp) == 2:                                # weights: MFMA sections cover the non-folded columns once
+            cnt = np.bincount(offs[:frag_end][ids[:frag_end] == tid], minlength=numel).reshape(shp)
+            if tid == 0:                                 # layers_xyz.0: cols 0..62 in fragments, 63..170 folded
+                assert np.all(cnt[:, :63] == 1) and np.all(cnt[:, 63:] == 0)
+            elif tid == 6:                               # layers_xyz.3: [pe 63 | cond 108 | h 256]
+                assert np.all(cnt[:, :63] == 1) and np.all(cnt[:, 63:171] == 0) and np.all(cnt[:, 171:] == 1)
+            elif tid == 16:                              # layers_dir.0: feat + the 8 rd_z columns in fragments
+                varying = [256 + 6 * f + 3 * sc for f in range(4) for sc in range(2)]
+                assert np.all(cnt[:, :256] == 1) and np.all(cnt[:, varying] == 1)
+                const = [c for c in range(256, 280) if c not in varying]
+                assert np.all(cnt[:, const] == 0)
+            else:
+                assert np.all(cnt == 1), tid
+        else:
+            cnt = np.bincount(offs[frag_end:][ids[frag_end:] == tid], minlength=numel)
+            assert np.all(cnt == 1), tid
+    # the folded columns are present exactly once in the conditioning matrices
+    cnt0 = np.bincount(offs[frag_end:][ids[frag_end:] == 0], minlength=256 * 171).reshape(256, 171)
+    assert np.all(cnt0[:, 63:] == 1) and np.all(cnt0[:, :63] == 0)
+
+
+def test_state_dict_schema_matches_reference_checkpoints():
+    import nerf
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False, use_viewdirs=True, num_layers=4,
+                                                        hidden_size=256, include_expression=True)
+    from oracle import nerface_oracle as O
+    sd = m.state_dict()
+    assert list(sd.keys()) == O.PAPER_KEYS
+    for k, shp in O.PAPER_SHAPES.items():
+        assert tuple(sd[k].shape) == shp and tuple(sd[k.replace("weight", "bias")].shape) == (shp[0],)
+    assert sum(v.numel() for v in sd.values()) == 568708
+    m.load_state_dict(O.init_paper_params(3))          # reference-style checkpoint dict round-trips
+    assert m.fused_supported()
+
+
+def test_product_has_no_cpu_path():
+    """CPU tensors must raise (no silent fallback), for the kernels and for the model's own forward."""
+    import nerf
+    from oracle import nerface_oracle as O
+    with pytest.raises(RuntimeError):
+        nerf.get_ray_bundle(4, 4, O.INTRINSICS, O.frame_pose(0))
+    with pytest.raises(RuntimeError):
+        nerf.positional_encoding(torch.zeros(3, 3), 10, True)
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_dir=False)
+    with pytest.raises(NotImplementedError):
+        m(torch.zeros(2, 87), torch.zeros(76), torch.zeros(32))
+
+
+def test_cfgnode_roundtrip():
+    import yaml
+    import nerf
+    src = dict(experiment=dict(id="x", train_iters=10), nerf=dict(use_viewdirs=True, train=dict(num_coarse=64, perturb=True, chunksize=2048)),
+               dataset=dict(no_ndc=True, near=0.2, far=0.8), models=dict(coarse=dict(type="ConditionalBlendshapePaperNeRFModel")))
+    cfg = nerf.CfgNode(src)
+    assert cfg.nerf.train.num_coarse == 64 and getattr(cfg.nerf, "train").perturb is True
+    assert getattr(nerf.models, cfg.models.coarse.type) is nerf.models.ConditionalBlendshapePaperNeRFModel
+    assert yaml.safe_load(cfg.dump()) == src
+    cfg.freeze()
+    with pytest.raises(AttributeError):
+        cfg.dataset.near = 1.0
+    c2 = cfg.clone()
+    c2.defrost()
+    c2.merge_from_list(["dataset.near", "0.5"])
+    assert c2.dataset.near == 0.5 and cfg.dataset.near == 0.2
+
+
+def test_public_api_names():
+    import inspect
+    import nerf
+    for n in ["CfgNode", "get_embedding_function", "get_ray_bundle", "img2mse", "mse2psnr", "meshgrid_xy", "models",
+              "run_one_iter_of_nerf", "load_flame_data", "load_llff_data", "dump_rays", "GaussianSmoothing",
+              "positional_encoding", "sample_pdf_2", "volume_render_radiance_field", "cumprod_exclusive", "get_minibatches",
+              "predict_and_render_radiance"]:
+        assert hasattr(nerf, n), n
+    sig = inspect.signature(nerf.run_one_iter_of_nerf)
+    assert list(sig.parameters) == ["height", "width", "focal_length", "model_coarse", "model_fine", "ray_origins",
+                                    "ray_directions", "options", "mode", "encode_position_fn", "encode_direction_fn",
+                                    "expressions", "background_prior", "latent_code", "ray_directions_ablation"]
+    assert list(inspect.signature(nerf.get_ray_bundle).parameters) == ["height", "width", "intrinsics", "tform_cam2world", "center"]
+    a, b = nerf.meshgrid_xy(torch.arange(3), torch.arange(2))
+    assert a.shape == (2, 3) and int(a[1, 2]) == 2 and int(b[1, 2]) == 1
+    assert abs(nerf.mse2psnr(0.01) - 20.0) < 1e-9
