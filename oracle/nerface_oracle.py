@@ -238,7 +238,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
     if n_fine <= 0:
         return rgb_c, disp_c, acc_c, None, None, None, w_c[:, -1]
     z_mid = 0.5 * (z[:, 1:] + z[:, :-1])
-    z_s = sample_pdf(z_mid, w_c[:, 1:-1], n_fine, u)
+    z_s = sample_pdf(z_mid, w_c[:, 1:-1], n_fine, u).detach()           # T:124: no gradient through the resampled depths
     z_f, _ = torch.sort(torch.cat((z, z_s), dim=-1), dim=-1)
     raw_f = paper_mlp(p_fine, encode_points(ro, rd, z_f, near, far), expr, latent).reshape(R, n_coarse + n_fine, 4).clone()
     st["raw_f_mlp"] = raw_f.clone()
