@@ -17,12 +17,7 @@
 //     the GEMMs: nf_paper_condition folds them into bias vectors (the `cond` table).
 #include <vector>
 #include <mutex>
-#include "nf_common.h"
-#include "nf_mlp_layout.h"
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-#define NF_MLP_WAVES 4
+#include "nf_mlp_dev.h"
 
 // =================================================================================================
 // pack: gather the 26 nn.Parameter storages into the fragment-ordered image
@@ -185,6 +180,7 @@ __global__ void __launch_bounds__(256) k_paper_condition(const float* __restrict
     __syncthreads();
     const float* bias = packed + OFF_BIAS;
     for (int i = blockIdx.x * blockDim.x + tid; i < COND_FLOATS; i += gridDim.x * blockDim.x) {
+        if (i >= B_CVEC) { cond[i] = i < B_DVEC ? cvec[i - B_CVEC] : dvec[i - B_DVEC]; continue; }
         float v = bias[i];
         if (i < B_L1 || (i >= B_L3 && i < B_L4)) {
             const int n = i < B_L1 ? i : i - B_L3;
@@ -213,119 +209,13 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // =================================================================================================
 // forward
 // =================================================================================================
-// Wave-private activation slab: [16*NT points][256 features]; the 16-byte fragment (feature/4 = q) of
-// point row p is stored at float4 index p*64 + (q ^ (p & 15)): ds_read_b128 / ds_write_b128 lane
-// groups then touch 16 distinct 16-byte bank slots (conflict-free, see nf_mlp_layout.h).
-__device__ __forceinline__ int nf_act_idx4(int prow, int q) { return prow * 64 + (q ^ (prow & 15)); }
-
-template <int NT>
-struct NfMlpState {
-    f32x4 acc[NT][16];
-};
-
-template <int NT, int NO>
-__device__ __forceinline__ void nf_load_w(f32x4 (&w)[NO], const f32x4* __restrict__ src, int lane) {
-#pragma unroll
-    for (int no = 0; no < NO; ++no) w[no] = src[no * 64 + lane];
-}
-
-template <int NT, int NO>
-__device__ __forceinline__ void nf_mma_chunk(f32x4 (&acc)[NT][16], const f32x4 (&w)[NO], const f32x4 (&b)[NT]) {
-#pragma unroll
-    for (int no = 0; no < NO; ++no)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-                acc[t][no] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[no][r], b[t][r], acc[t][no], 0, 0, 0);
-}
-
-// K chunks whose B fragments come from registers (PE / dir slots); NCH is small and fully unrolled.
-template <int NT, int NO, int NCH>
-__device__ __forceinline__ void nf_mma_from_regs(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, const f32x4 (&breg)[NT][NCH],
-                                                 int lane) {
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        f32x4 w[NO];
-        nf_load_w<NT, NO>(w, wsec + (size_t)j * NO * 64, lane);
-        f32x4 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = breg[t][j];
-        nf_mma_chunk<NT, NO>(acc, w, b);
-    }
-}
-
-// K chunks whose B fragments come from the wave's LDS slab; weights are register double-buffered one
-// chunk ahead.  nch must be even.
-template <int NT, int NO>
-__device__ __forceinline__ void nf_mma_from_lds(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch,
-                                                const f32x4* act4, int lane) {
-    const int g = lane >> 4, c = lane & 15;
-    f32x4 wa[NO], wb[NO];
-    nf_load_w<NT, NO>(wa, wsec, lane);
-#pragma unroll 1
-    for (int ni = 0; ni < nch; ni += 2) {
-        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
-        f32x4 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
-        nf_mma_chunk<NT, NO>(acc, wa, b);
-        if (ni + 2 < nch) nf_load_w<NT, NO>(wa, wsec + (size_t)(ni + 2) * NO * 64, lane);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
-        nf_mma_chunk<NT, NO>(acc, wb, b);
-    }
-}
-
-template <int NT, int NO>
-__device__ __forceinline__ void nf_init_acc(f32x4 (&acc)[NT][16], const float* __restrict__ bias, int lane) {
-    const int g = lane >> 4;
-#pragma unroll
-    for (int no = 0; no < NO; ++no) {
-        const f32x4 b = *reinterpret_cast<const f32x4*>(bias + 16 * no + 4 * g);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t][no] = b;
-    }
-}
-
-template <int NT, int NO, bool RELU>
-__device__ __forceinline__ void nf_store_act(const f32x4 (&acc)[NT][16], f32x4* act4, int lane) {
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int no = 0; no < NO; ++no)
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 v = acc[t][no];
-            if (RELU) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-            act4[nf_act_idx4(16 * t + c, 4 * no + g)] = v;
-        }
-}
-
-// Positional encoding of one point in B-fragment order (see nfl::pe_slot_pair).
-__device__ __forceinline__ void nf_encode_point(float px, float py, float pz, int g, f32x4 (&pe)[4]) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float v[4];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int pidx = (g < 3 ? g * 8 : 24) + j * 2 + h;
-            const int freq = pidx / 3, comp = pidx - 3 * freq;
-            const float x = comp == 0 ? px : (comp == 1 ? py : pz);
-            float s, cs;
-            sincosf(nf_mul(x, (float)(1 << freq)), &s, &cs);
-            v[2 * h] = s;
-            v[2 * h + 1] = cs;
-        }
-        if (j == 3 && g == 3) { v[0] = px; v[1] = py; v[2] = pz; v[3] = 0.0f; }
-        pe[j] = (f32x4){v[0], v[1], v[2], v[3]};
-    }
-}
-
-template <int NT>
+// SAVE = training forward: every layer output is also written to the `saved` buffer (layout nfl::S_*),
+// from which the backward chain takes its ReLU masks and the weight-gradient GEMMs their right operands.
+template <int NT, bool SAVE>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z,
-                int64_t n_points, int S, float* __restrict__ raw) {
+                int64_t n_points, int S, float* __restrict__ raw, float* __restrict__ saved) {
     using namespace nfl;
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -352,36 +242,47 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+        if (SAVE && p0 + 16 * t + c < n_points) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(saved + S_PE * n_points + p * 64 + 16 * j + 4 * g) = pe[t][j];
+            *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
+        }
     }
 
     f32x4 acc[NT][16];
+#define NF_FINISH_LAYER(NO_, RELU_, SEC_, WIDTH_)                                                   \
+    do {                                                                                            \
+        if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                   \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                              \
+        if (SAVE) nf_store_global<NT, NO_>(acc, saved + (int64_t)(SEC_) * n_points, WIDTH_, p0, n_points, lane); \
+    } while (0)
     // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
     nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H0, 256);
     // ---- layers_xyz.1, .2 ------------------------------------------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_L1 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H1, 256);
     nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_L2 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H2, 256);
     // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
     nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H3, 256);
     // ---- layers_xyz.4, .5 ------------------------------------------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_L4 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H4, 256);
     nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_L5 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_FINISH_LAYER(16, true, S_H5, 256);
     // ---- fc_feat (no activation, M:250) ------------------------------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
-    nf_store_act<NT, 16, false>(acc, act4, lane);
+    NF_FINISH_LAYER(16, false, S_FEAT, 256);
     // ---- layers_dir.0 : [feat | dir slots] -> 128, ReLU; tile 8 row 0 = fc_alpha(feat) (Q2) ----------
     nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
     nf_mma_from_lds<NT, 9>(acc, W + OFF_D0 / 4, 16, act4, lane);
@@ -389,14 +290,15 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     float sigma_raw[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
-    nf_store_act<NT, 8, true>(acc, act4, lane);
+    NF_FINISH_LAYER(8, true, S_D0, 128);
     // ---- layers_dir.1, .2 -----------------------------------------------------------------------------
     nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
     nf_mma_from_lds<NT, 8>(acc, W + OFF_D1 / 4, 8, act4, lane);
-    nf_store_act<NT, 8, true>(acc, act4, lane);
+    NF_FINISH_LAYER(8, true, S_D1, 128);
     nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
     nf_mma_from_lds<NT, 8>(acc, W + OFF_D2 / 4, 8, act4, lane);
-    nf_store_act<NT, 8, true>(acc, act4, lane);
+    NF_FINISH_LAYER(8, true, S_D2, 128);
+#undef NF_FINISH_LAYER
     // ---- fc_rgb -------------------------------------------------------------------------------------------
     nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
     nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
@@ -410,16 +312,34 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
 }
 
-extern "C" int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
-                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+static int nf_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                         const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (!packed || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;
-    constexpr int NT = 2;
+    constexpr int NT = NF_MLP_NT;
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    hipLaunchKernelGGL(k_paper_mlp_fwd<NT>, dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro, rd,
-                       rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+    if (saved)
+        hipLaunchKernelGGL((k_paper_mlp_fwd<NT, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
+    else
+        hipLaunchKernelGGL((k_paper_mlp_fwd<NT, false>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, (float*)nullptr);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    return nf_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, nullptr, stream);
+}
+
+extern "C" size_t nf_paper_saved_floats(int64_t n_points) { return (size_t)nfl::SAVED_PER_POINT * (size_t)n_points; }
+
+extern "C" int nf_paper_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd,
+                                      const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                                      float* saved, nf_stream_t stream) {
+    if (!saved) return NF_EINVAL;
+    return nf_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, saved, stream);
 }

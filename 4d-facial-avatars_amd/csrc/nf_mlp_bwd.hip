@@ -1,0 +1,494 @@
+// K4 backward: gradients of the fused paper MLP w.r.t. all of its parameters and the latent code
+// (reference: autograd through nerf/models.py:236-261; what is learnable is listed in SURVEY §8 A12).
+//
+// Three stages, all on exact-f32 MFMA (v_mfma_f32_16x16x4_f32):
+//   B1  k_paper_mlp_bwd_chain   per 32-point wave tile, the forward kernel run in reverse on a transposed
+//                               fragment image: dZ_l = (dZ_{l+1} . W_{l+1}) * [X_l > 0]; masks come from the
+//                               activations the training forward saved; every dZ_l is written to HBM.
+//   B2  k_paper_dw_gemm         dW_l = dZ_l^T . X_{l-1} as wave-level 128x128 output tiles with the point
+//                               dimension (hundreds of thousands) split into slices; bias grads (column sums
+//                               of dZ) fall out of the A fragments.  Deterministic: partial slabs per slice.
+//   B3  k_paper_grad_reduce /   sum the slabs over slices, then scatter into the 26 reference-layout tensors:
+//       k_paper_grad_unpack     PE slot order -> reference columns, folded conditioning columns as outer
+//                               products (db (x) [expr/3 | latent]), d latent = W[:,139:171]^T db.
+#include <vector>
+#include <mutex>
+#include "nf_mlp_dev.h"
+
+struct NfParamPtrs26 { const float* p[NF_PAPER_NUM_PARAMS]; };
+
+// =================================================================================================
+// transposed pack
+// =================================================================================================
+static const uint32_t NF_ZERO_CODE_T = 0xFF000000u;
+static inline uint32_t nf_code_t(int tensor, int row, int col, int ncols) { return ((uint32_t)tensor << 24) | (uint32_t)(row * ncols + col); }
+
+// block (ni, no), lane (g, i), r  ->  W[row = 16 ni + 4 g + r][col0 + 16 no + i]
+static void nf_fill_layer_t(std::vector<uint32_t>& t, int off, int nk, int no_tiles, int tensor, int n_rows, int n_cols, int col0) {
+    for (int ni = 0; ni < nk; ++ni)
+        for (int no = 0; no < no_tiles; ++no)
+            for (int lane = 0; lane < 64; ++lane)
+                for (int r = 0; r < 4; ++r) {
+                    const int g = lane >> 4, i = lane & 15;
+                    const int row = 16 * ni + 4 * g + r, col = col0 + 16 * no + i;
+                    t[(size_t)off + ((size_t)(ni * no_tiles + no) * 64 + lane) * 4 + r] =
+                        row < n_rows ? nf_code_t(tensor, row, col, n_cols) : NF_ZERO_CODE_T;
+                }
+}
+
+static void nf_build_gather_table_t(std::vector<uint32_t>& t) {
+    using namespace nfl;
+    t.assign(PACKED_T_FLOATS, NF_ZERO_CODE_T);
+    nf_fill_layer_t(t, OFFT_RGB, 1, 8, 24, 3, 128, 0);            // fc_rgb.weight (3,128)
+    nf_fill_layer_t(t, OFFT_D2, 8, 8, 20, 128, 128, 0);           // layers_dir.2
+    nf_fill_layer_t(t, OFFT_D1, 8, 8, 18, 128, 128, 0);           // layers_dir.1
+    nf_fill_layer_t(t, OFFT_D0, 8, 16, 16, 128, 280, 0);          // layers_dir.0[:, :256]
+    nf_fill_layer_t(t, OFFT_D0 + 8 * 16 * FRAG, 1, 16, 14, 1, 256, 0);   // chunk 8: slot 0 = fc_alpha.weight (1,256)
+    nf_fill_layer_t(t, OFFT_FEAT, 16, 16, 12, 256, 256, 0);       // fc_feat
+    nf_fill_layer_t(t, OFFT_L5, 16, 16, 10, 256, 256, 0);
+    nf_fill_layer_t(t, OFFT_L4, 16, 16, 8, 256, 256, 0);
+    nf_fill_layer_t(t, OFFT_L3, 16, 16, 6, 256, 427, 171);        // layers_xyz.3[:, 171:427]
+    nf_fill_layer_t(t, OFFT_L2, 16, 16, 4, 256, 256, 0);
+    nf_fill_layer_t(t, OFFT_L1, 16, 16, 2, 256, 256, 0);
+}
+
+__global__ void __launch_bounds__(256) k_paper_pack_t(NfParamPtrs26 ptrs, const uint32_t* __restrict__ table,
+                                                      float* __restrict__ packed, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t code = table[i];
+        const uint32_t id = code >> 24;
+        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+    }
+}
+
+static std::mutex g_table_t_mutex;
+static uint32_t* g_table_t_dev[64] = {nullptr};
+
+static int nf_get_table_t(uint32_t** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    std::lock_guard<std::mutex> lock(g_table_t_mutex);
+    if (!g_table_t_dev[dev]) {
+        std::vector<uint32_t> host;
+        nf_build_gather_table_t(host);
+        uint32_t* d = nullptr;
+        e = hipMalloc(&d, host.size() * sizeof(uint32_t));
+        if (e != hipSuccess) return (int)e;
+        e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
+        g_table_t_dev[dev] = d;
+    }
+    *out = g_table_t_dev[dev];
+    return 0;
+}
+
+extern "C" size_t nf_paper_packed_bwd_floats(void) { return (size_t)nfl::PACKED_T_FLOATS; }
+
+extern "C" int nf_paper_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream) {
+    if (!params || !packed_t) return NF_EINVAL;
+    NfParamPtrs26 ptrs;
+    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) {
+        if (!params[i]) return NF_EINVAL;
+        ptrs.p[i] = params[i];
+    }
+    uint32_t* table = nullptr;
+    const int rc = nf_get_table_t(&table);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_paper_pack_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, packed_t, (int)nfl::PACKED_T_FLOATS);
+    NF_RETURN_LAUNCH();
+}
+
+// =================================================================================================
+// B1: backward chain
+// =================================================================================================
+template <int NT, int NO>
+__device__ __forceinline__ void nf_zero_acc(f32x4 (&acc)[NT][16]) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][no] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// acc *= [X > 0] with X read from the saved activations ([n_points][width] row-major)
+template <int NT, int NO>
+__device__ __forceinline__ void nf_mask_by_saved(f32x4 (&acc)[NT][16], const float* __restrict__ sec, int width, int64_t p0,
+                                                 int64_t n_points, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(sec + p * width + 16 * no + 4 * g);
+            f32x4 v = acc[t][no];
+            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+            acc[t][no] = v;
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_paper_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
+                      int64_t n_points, float* __restrict__ dz) {
+    using namespace nfl;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
+    const int64_t n = n_points;
+
+    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int64_t p = p0 + 16 * t + c;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
+        frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
+        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[NT][16];
+#define NF_BWD_FINISH(NO_, MASKSEC_, MASKW_, ZSEC_)                                                     \
+    do {                                                                                                \
+        if ((MASKSEC_) >= 0) nf_mask_by_saved<NT, NO_>(acc, saved + (int64_t)(MASKSEC_) * n, MASKW_, p0, n, lane); \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
+        nf_store_global<NT, NO_>(acc, dz + (int64_t)(ZSEC_) * n, (NO_) * 16, p0, n, lane);              \
+    } while (0)
+    // d(layers_dir.2 out) = d rgb . fc_rgb.weight ; mask by layers_dir.2's ReLU
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
+    NF_BWD_FINISH(8, S_D2, 128, Z_D2);
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_lds<NT, 8>(acc, WT + OFFT_D2 / 4, 8, act4, lane);
+    NF_BWD_FINISH(8, S_D1, 128, Z_D1);
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_lds<NT, 8>(acc, WT + OFFT_D1 / 4, 8, act4, lane);
+    NF_BWD_FINISH(8, S_D0, 128, Z_D0);
+    // d feat = dZ_D0 . layers_dir.0.weight[:, :256] + d sigma * fc_alpha.weight   (no activation on feat)
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_D0 / 4, 8, act4, lane);
+    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_D0 / 4 + 8 * 16 * 64, frag_sig, lane);
+    NF_BWD_FINISH(16, -1, 256, Z_FEAT);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_FEAT / 4, 16, act4, lane);
+    NF_BWD_FINISH(16, S_H5, 256, Z_L5);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L5 / 4, 16, act4, lane);
+    NF_BWD_FINISH(16, S_H4, 256, Z_L4);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L4 / 4, 16, act4, lane);
+    NF_BWD_FINISH(16, S_H3, 256, Z_L3);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L3 / 4, 16, act4, lane);     // hidden columns of the skip layer only
+    NF_BWD_FINISH(16, S_H2, 256, Z_L2);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L2 / 4, 16, act4, lane);
+    NF_BWD_FINISH(16, S_H1, 256, Z_L1);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L1 / 4, 16, act4, lane);
+    NF_BWD_FINISH(16, S_H0, 256, Z_L0);
+#undef NF_BWD_FINISH
+}
+
+// =================================================================================================
+// B2: weight-gradient GEMMs.   One WAVE = one job: a 128 x 128 tile of  dW = A^T B  over one point slice.
+//   A = dZ (or d_raw) [points][lda], B = saved activations [points][ldb].
+//   MFMA: D[n][k] += A[n][pt] * B[pt][k]; step r of a 16-point chunk takes from lane group g the point
+//   chunk + 4 r + g; lane (g, i) therefore issues dword loads of 16 consecutive floats per row (64 B).
+// =================================================================================================
+struct NfDwJob {
+    int a_kind;      // 0: dz section, 1: d_raw
+    int a_sec;       // section offset (floats per point) within dz
+    int lda, a_col0, n_valid;
+    int b_sec, ldb, b_col0, k_valid;
+    int out_off, ldo;
+    int cs_off;      // >= 0: also write column sums of A (bias grads) for this n-block
+};
+
+#define NF_DW_JOBS 36
+__constant__ NfDwJob c_dw_jobs[NF_DW_JOBS];
+
+static void nf_build_dw_jobs(NfDwJob* j) {
+    using namespace nfl;
+    int n = 0;
+    auto add = [&](int a_kind, int a_sec, int lda, int a_col0, int n_valid, int b_sec, int ldb, int b_col0, int k_valid,
+                   int out_off, int ldo, int cs_off) {
+        j[n++] = NfDwJob{a_kind, a_sec, lda, a_col0, n_valid, b_sec, ldb, b_col0, k_valid, out_off, ldo, cs_off};
+    };
+    // a full 256 x K layer: n-blocks {0,1} x k-blocks
+    auto layer256 = [&](int zsec, int bsec, int ldb, int kdim, int gout, int cs) {
+        for (int nb = 0; nb < 2; ++nb)
+            for (int kb = 0; kb * 128 < kdim; ++kb)
+                add(0, zsec, 256, 128 * nb, 128, bsec, ldb, 128 * kb, kdim - 128 * kb < 128 ? kdim - 128 * kb : 128,
+                    gout + 128 * nb * kdim + 128 * kb, kdim, (kb == 0 && cs >= 0) ? cs + 128 * nb : -1);
+    };
+    layer256(Z_L0, S_PE, 64, 64, G_L0, CS_L0 + 0);
+    layer256(Z_L1, S_H0, 256, 256, G_L1, CS_L0 + 256);
+    layer256(Z_L2, S_H1, 256, 256, G_L2, CS_L0 + 512);
+    layer256(Z_L3, S_PE, 64, 64, G_L3A, CS_L0 + 768);
+    layer256(Z_L3, S_H2, 256, 256, G_L3B, -1);
+    layer256(Z_L4, S_H3, 256, 256, G_L4, CS_L0 + 1024);
+    layer256(Z_L5, S_H4, 256, 256, G_L5, CS_L0 + 1280);
+    layer256(Z_FEAT, S_H5, 256, 256, G_FEAT, CS_L0 + 1536);
+    add(0, Z_D0, 128, 0, 128, S_FEAT, 256, 0, 128, G_D0A, 256, CS_D0);
+    add(0, Z_D0, 128, 0, 128, S_FEAT, 256, 128, 128, G_D0A + 128, 256, -1);
+    add(0, Z_D0, 128, 0, 128, S_DIRF, 16, 0, 16, G_D0B, 16, -1);
+    add(0, Z_D1, 128, 0, 128, S_D0, 128, 0, 128, G_D1, 128, CS_D0 + 128);
+    add(0, Z_D2, 128, 0, 128, S_D1, 128, 0, 128, G_D2, 128, CS_D0 + 256);
+    add(1, 0, 4, 0, 4, S_D2, 128, 0, 128, G_RGB, 128, CS_RGB);             // rows 0..2: fc_rgb.weight; cs[3] = d b_alpha
+    add(1, 0, 4, 3, 1, S_FEAT, 256, 0, 128, G_ALPHA, 256, -1);             // row 0: fc_alpha.weight
+    add(1, 0, 4, 3, 1, S_FEAT, 256, 128, 128, G_ALPHA + 128, 256, -1);
+    // n == NF_DW_JOBS by construction
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_paper_dw_gemm(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
+                int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
+    using namespace nfl;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, i = lane & 15;
+    const int jid = blockIdx.x * 4 + wave;
+    const int slice = blockIdx.y;
+    if (jid >= NF_DW_JOBS) return;
+    const NfDwJob job = c_dw_jobs[jid];
+    const int64_t p_begin = (int64_t)slice * pts_per_slice;
+    int64_t p_end = p_begin + pts_per_slice;
+    if (p_end > n_points) p_end = n_points;
+    const float* A = (job.a_kind ? d_raw : dz + (int64_t)job.a_sec * n_points) + job.a_col0;
+    const float* B = saved + (int64_t)job.b_sec * n_points + job.b_col0;
+    float* out = slabs + (int64_t)slice * SLAB_FLOATS + job.out_off;
+    const int lda = job.lda, ldb = job.ldb;
+
+    // which of the 8 n-tiles / k-tiles hold valid columns for this lane
+    bool a_ok[8], b_ok[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) { a_ok[q] = 16 * q + i < job.n_valid; b_ok[q] = 16 * q + i < job.k_valid; }
+
+    f32x4 acc[8][8];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 8; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float cs[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+
+    float a[8][4], b[8][4];
+    auto load_chunk = [&](int64_t p, float (&aa)[8][4], float (&bb)[8][4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = p + 4 * r + g;
+            const bool rv = row < p_end;
+            const float* ar = A + row * lda + i;
+            const float* br = B + row * ldb + i;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                aa[q][r] = (rv && a_ok[q]) ? ar[16 * q] : 0.f;
+                bb[q][r] = (rv && b_ok[q]) ? br[16 * q] : 0.f;
+            }
+        }
+    };
+    float an[8][4], bn[8][4];
+    if (p_begin < p_end) load_chunk(p_begin, a, b);
+    for (int64_t p = p_begin; p < p_end; p += 16) {
+        const bool more = p + 16 < p_end;
+        if (more) load_chunk(p + 16, an, bn);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) {
+                cs[nt] += a[nt][r];
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][r], b[kt][r], acc[nt][kt], 0, 0, 0);
+            }
+        if (more) {
+#pragma unroll
+            for (int q = 0; q < 8; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { a[q][r] = an[q][r]; b[q][r] = bn[q][r]; }
+        }
+    }
+    // D layout: lane (g, c = i): rows n = 16 nt + 4 g + r, column k = 16 kt + i
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nrow = 16 * nt + 4 * g + r;
+            if (nrow < job.n_valid) {
+#pragma unroll
+                for (int kt = 0; kt < 8; ++kt)
+                    if (b_ok[kt]) out[(int64_t)nrow * job.ldo + 16 * kt + i] = acc[nt][kt][r];
+            }
+        }
+    if (job.cs_off >= 0) {
+        float* cso = slabs + (int64_t)slice * SLAB_FLOATS + job.cs_off;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float v = cs[q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (g == 0 && a_ok[q]) cso[16 * q + i] = v;
+        }
+    }
+}
+
+// =================================================================================================
+// B3: reduce over slices + scatter to the reference parameter layout
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_paper_grad_reduce(const float* __restrict__ slabs, int n_slices, float* __restrict__ sum) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfl::SLAB_FLOATS; e += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < n_slices; ++k) s += slabs[(int64_t)k * nfl::SLAB_FLOATS + e];
+        sum[e] = s;
+    }
+}
+
+struct NfGradOffsets { int off[NF_PAPER_NUM_PARAMS + 1]; };
+
+// inverse of nfl::pe_slot_to_col: reference PE column (0..62) -> slot
+__device__ __forceinline__ int nf_pe_col_to_slot(int col) {
+    if (col < 3) return 16 * 3 + 4 * 3 + col;                       // raw xyz: chunk 3, group 3, r = col
+    const int q = col - 3, freq = q / 6, rem = q - 6 * freq, sc = rem / 3, comp = rem - 3 * sc;
+    const int pidx = 3 * freq + comp;
+    int g, j, h;
+    if (pidx < 24) { g = pidx >> 3; j = (pidx & 7) >> 1; h = pidx & 1; }
+    else { g = 3; j = (pidx - 24) >> 1; h = (pidx - 24) & 1; }
+    return 16 * j + 4 * g + 2 * h + sc;
+}
+
+__global__ void __launch_bounds__(256) k_paper_grad_unpack(const float* __restrict__ sum, const float* __restrict__ packed,
+                                                           const float* __restrict__ cond, NfGradOffsets offs,
+                                                           float* __restrict__ grads) {
+    using namespace nfl;
+    const float* cvec = cond + B_CVEC;
+    const float* dvec = cond + B_DVEC;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < GRAD_FLOATS; e += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (e >= GRAD_PARAM_FLOATS) {                                // d latent_j = sum_n W0[n][139+j] db0[n] + W3[n][139+j] db3[n]
+            const int j = e - GRAD_PARAM_FLOATS;
+            const float* w0 = packed + OFF_WC0 + 76 + j;
+            const float* w3 = packed + OFF_WC3 + 76 + j;
+            for (int n = 0; n < 256; ++n) v += w0[n * NCOND] * sum[CS_L0 + n] + w3[n * NCOND] * sum[CS_L0 + 768 + n];
+            grads[e] = v;
+            continue;
+        }
+        int t = 0;
+        while (e >= offs.off[t + 1]) ++t;
+        const int local = e - offs.off[t];
+        switch (t) {
+            case 0: {  // layers_xyz.0.weight [256][171]
+                const int n = local / 171, col = local - 171 * n;
+                v = col < 63 ? sum[G_L0 + n * 64 + nf_pe_col_to_slot(col)] : sum[CS_L0 + n] * cvec[col - 63];
+            } break;
+            case 1: v = sum[CS_L0 + local]; break;
+            case 2: v = sum[G_L1 + local]; break;
+            case 3: v = sum[CS_L0 + 256 + local]; break;
+            case 4: v = sum[G_L2 + local]; break;
+            case 5: v = sum[CS_L0 + 512 + local]; break;
+            case 6: {  // layers_xyz.3.weight [256][427] = [pe 63 | cond 108 | hidden 256]
+                const int n = local / 427, col = local - 427 * n;
+                v = col < 63 ? sum[G_L3A + n * 64 + nf_pe_col_to_slot(col)]
+                             : (col < 171 ? sum[CS_L0 + 768 + n] * cvec[col - 63] : sum[G_L3B + n * 256 + (col - 171)]);
+            } break;
+            case 7: v = sum[CS_L0 + 768 + local]; break;
+            case 8: v = sum[G_L4 + local]; break;
+            case 9: v = sum[CS_L0 + 1024 + local]; break;
+            case 10: v = sum[G_L5 + local]; break;
+            case 11: v = sum[CS_L0 + 1280 + local]; break;
+            case 12: v = sum[G_FEAT + local]; break;
+            case 13: v = sum[CS_L0 + 1536 + local]; break;
+            case 14: v = sum[G_ALPHA + local]; break;          // fc_alpha.weight [1][256]
+            case 15: v = sum[CS_RGB + 3]; break;               // fc_alpha.bias
+            case 16: {  // layers_dir.0.weight [128][280] = [feat 256 | PE4(rd_z, near, far) 24]
+                const int n = local / 280, col = local - 280 * n;
+                if (col < 256) v = sum[G_D0A + n * 256 + col];
+                else {
+                    const int q = col - 256, f = q / 6, rem = q - 6 * f, sc = rem / 3, comp = rem - 3 * sc;
+                    v = comp == 0 ? sum[G_D0B + n * 16 + 4 * f + sc] : sum[CS_D0 + n] * dvec[4 * f + 2 * sc + (comp - 1)];
+                }
+            } break;
+            case 17: v = sum[CS_D0 + local]; break;
+            case 18: v = sum[G_D1 + local]; break;
+            case 19: v = sum[CS_D0 + 128 + local]; break;
+            case 20: v = sum[G_D2 + local]; break;
+            case 21: v = sum[CS_D0 + 256 + local]; break;
+            case 22: case 23: v = 0.f; break;                   // layers_dir.3: never used (Quirk Q3)
+            case 24: v = sum[G_RGB + local]; break;             // fc_rgb.weight [3][128]
+            case 25: v = sum[CS_RGB + local]; break;
+        }
+        grads[e] = v;
+    }
+}
+
+static const int NF_PARAM_NUMEL[NF_PAPER_NUM_PARAMS] = {
+    256 * 171, 256, 65536, 256, 65536, 256, 256 * 427, 256, 65536, 256, 65536, 256,   // layers_xyz.0..5
+    65536, 256, 256, 1,                                                              // fc_feat, fc_alpha
+    128 * 280, 128, 16384, 128, 16384, 128, 16384, 128,                              // layers_dir.0..3
+    384, 3};                                                                         // fc_rgb
+
+extern "C" size_t nf_paper_grad_floats(void) { return (size_t)nfl::GRAD_FLOATS; }
+
+static void nf_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
+    int64_t pps = (n_points + 27) / 28;
+    pps = (pps + 15) / 16 * 16;
+    if (pps < 1024) pps = 1024;
+    *pts_per_slice = pps;
+    *n_slices = (int)((n_points + pps - 1) / pps);
+}
+
+extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
+    int64_t pps; int ns;
+    nf_bwd_plan(n_points, &pps, &ns);
+    return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS;
+}
+
+static std::once_flag g_jobs_once[64];
+
+extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved,
+                                const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                float* grads, nf_stream_t stream) {
+    using namespace nfl;
+    if (!packed || !packed_t || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0) return NF_EINVAL;
+    const int64_t n_points = n_rays * n_samples;
+    if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    int rc = 0;
+    std::call_once(g_jobs_once[dev], [&]() {
+        NfDwJob jobs[NF_DW_JOBS];
+        nf_build_dw_jobs(jobs);
+        hipError_t ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dw_jobs), jobs, sizeof(jobs));
+        if (ee != hipSuccess) rc = (int)ee;
+    });
+    if (rc) return rc;
+    int64_t pps; int ns;
+    nf_bwd_plan(n_points, &pps, &ns);
+    float* dz = workspace;
+    float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
+    float* sum = slabs + (size_t)ns * SLAB_FLOATS;
+    hipStream_t s = nf_s(stream);
+    constexpr int NT = NF_MLP_NT;
+    const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
+    const int64_t grid = (n_points + per_block - 1) / per_block;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
+                       n_points, dz);
+    hipLaunchKernelGGL(k_paper_dw_gemm, dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, dz, d_raw, saved, n_points, pps, slabs);
+    hipLaunchKernelGGL(k_paper_grad_reduce, dim3(512), dim3(256), 0, s, slabs, ns, sum);
+    NfGradOffsets offs;
+    offs.off[0] = 0;
+    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];
+    hipLaunchKernelGGL(k_paper_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
+    NF_RETURN_LAUNCH();
+}

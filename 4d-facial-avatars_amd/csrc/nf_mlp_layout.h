@@ -48,8 +48,24 @@ constexpr int OFF_BIAS = OFF_WCD + 128 * 16;    // un-folded bias table, same la
 constexpr int B_L0 = 0, B_L1 = 256, B_L2 = 512, B_L3 = 768, B_L4 = 1024, B_L5 = 1280, B_FEAT = 1536;
 constexpr int B_D0 = 1792;                      // 128 + 16 (alpha tile: [fc_alpha.bias, 0 x 15])
 constexpr int B_D1 = B_D0 + 144, B_D2 = B_D1 + 128, B_RGB = B_D2 + 128;   // rgb tile: [b_r, b_g, b_b, 0 x 13]
-constexpr int COND_FLOATS = B_RGB + 16;         // 2208
-constexpr int PACKED_FLOATS = OFF_BIAS + COND_FLOATS;
+constexpr int BIAS_FLOATS = B_RGB + 16;         // 2208 (the bias table proper)
+constexpr int B_CVEC = BIAS_FLOATS;             // cond only: [expr*1/3 (76) | latent (32)] as the kernels used it
+constexpr int B_DVEC = B_CVEC + NCOND;          // cond only: PE4 of (near, far): index 4f + 2sc + (0: near, 1: far)
+constexpr int COND_FLOATS = B_DVEC + 16;        // 2332
+constexpr int PACKED_FLOATS = OFF_BIAS + BIAS_FLOATS;
+
+// ---- training: activations saved by the forward, floats per point ---------------------------------------
+// Section X of a buffer for n points starts at X * n and is an [n][width] row-major matrix.
+constexpr int S_PE = 0;                          // 64, PE slot order (see pe_slot_to_col)
+constexpr int S_H0 = 64, S_H1 = 320, S_H2 = 576, S_H3 = 832, S_H4 = 1088, S_H5 = 1344;   // 256 each, post-ReLU
+constexpr int S_FEAT = 1600;                     // 256, fc_feat output
+constexpr int S_D0 = 1856, S_D1 = 1984, S_D2 = 2112;                                     // 128 each, post-ReLU
+constexpr int S_DIRF = 2240;                     // 16, dir slot order: (sin, cos, 0, 0)(rd_z 2^g), g = 0..3
+constexpr int SAVED_PER_POINT = 2256;
+// ---- training: pre-activation gradients written by the backward chain, floats per point ------------------
+constexpr int Z_L0 = 0, Z_L1 = 256, Z_L2 = 512, Z_L3 = 768, Z_L4 = 1024, Z_L5 = 1280, Z_FEAT = 1536;
+constexpr int Z_D0 = 1792, Z_D1 = 1920, Z_D2 = 2048;
+constexpr int DZ_PER_POINT = 2176;
 
 // ---- PE slot permutation ---------------------------------------------------------------------------
 // PE slot s = 16*j + 4*g + r (chunk j, lane group g, step r).  Lane groups 0..2 hold 8 (freq, comp)
@@ -68,4 +84,49 @@ __host__ __device__ inline int pe_slot_to_col(int slot) {                     //
     return r < 3 ? r : -1;
 }
 
+}  // namespace nfl
+
+namespace nfl {
+// ---- transposed fragment image for the backward chain dX = dZ . W ("packed_t") ------------------------
+// Section layout [ni][no][lane][4] as in the forward image, but a block (ni, no) now holds
+// W[16*ni + 4*g + r][col0 + 16*no + i]: the reduction runs over the layer's OUTPUT features.
+//                       reduction chunks                 output tiles
+// T_RGB  fc_rgb         1 (slots 0..2 = d rgb)           8   -> d(layers_dir.2 out)
+// T_D2, T_D1            8                                8
+// T_D0   layers_dir.0   8 + 1 (slot 0 = d sigma, fc_alpha.weight)   16  -> d feat   (columns 0..255 only)
+// T_FEAT, T_L5, T_L4, T_L3 (columns 171..426), T_L2, T_L1          16 x 16
+constexpr int OFFT_RGB = 0;
+constexpr int OFFT_D2 = OFFT_RGB + 1 * 8 * FRAG;
+constexpr int OFFT_D1 = OFFT_D2 + 8 * 8 * FRAG;
+constexpr int OFFT_D0 = OFFT_D1 + 8 * 8 * FRAG;
+constexpr int OFFT_FEAT = OFFT_D0 + 9 * 16 * FRAG;
+constexpr int OFFT_L5 = OFFT_FEAT + 16 * 16 * FRAG;
+constexpr int OFFT_L4 = OFFT_L5 + 16 * 16 * FRAG;
+constexpr int OFFT_L3 = OFFT_L4 + 16 * 16 * FRAG;
+constexpr int OFFT_L2 = OFFT_L3 + 16 * 16 * FRAG;
+constexpr int OFFT_L1 = OFFT_L2 + 16 * 16 * FRAG;
+constexpr int PACKED_T_FLOATS = OFFT_L1 + 16 * 16 * FRAG;
+
+// ---- per-slice partial-gradient slab written by the weight-gradient GEMMs --------------------------------
+constexpr int G_L0 = 0;                          // [256][64]   (PE slot order)
+constexpr int G_L1 = G_L0 + 256 * 64;            // [256][256]
+constexpr int G_L2 = G_L1 + 65536;
+constexpr int G_L3A = G_L2 + 65536;              // [256][64]   (PE slot order)
+constexpr int G_L3B = G_L3A + 256 * 64;          // [256][256]  (hidden part, reference columns 171..426)
+constexpr int G_L4 = G_L3B + 65536;
+constexpr int G_L5 = G_L4 + 65536;
+constexpr int G_FEAT = G_L5 + 65536;
+constexpr int G_D0A = G_FEAT + 65536;            // [128][256]
+constexpr int G_D0B = G_D0A + 128 * 256;         // [128][16]   (dir slot order)
+constexpr int G_D1 = G_D0B + 128 * 16;           // [128][128]
+constexpr int G_D2 = G_D1 + 128 * 128;
+constexpr int G_RGB = G_D2 + 128 * 128;          // [16][128]   rows 0..2 = fc_rgb.weight grad
+constexpr int G_ALPHA = G_RGB + 16 * 128;        // [16][256]   row 0 = fc_alpha.weight grad
+constexpr int CS_L0 = G_ALPHA + 16 * 256;        // column sums of dZ = bias grads: 7 x 256
+constexpr int CS_D0 = CS_L0 + 7 * 256;           // 3 x 128
+constexpr int CS_RGB = CS_D0 + 3 * 128;          // 16: [d b_r, d b_g, d b_b, d b_alpha, 0...]
+constexpr int SLAB_FLOATS = CS_RGB + 16;
+
+constexpr int GRAD_PARAM_FLOATS = 568708;        // the 26 tensors, state_dict order, flattened
+constexpr int GRAD_FLOATS = GRAD_PARAM_FLOATS + 32;   // + d latent
 }  // namespace nfl

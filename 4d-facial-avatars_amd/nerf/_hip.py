@@ -31,10 +31,13 @@ _PROTOTYPES = {
     "nf_paper_pack": (C.c_int, [_P, _P, _P]),
     "nf_paper_condition": (C.c_int, [_P, _P, _P, _F, _F, _P, _P]),
     "nf_paper_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
-    "nf_paper_mlp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P, _Z, _P]),
-    "nf_paper_bwd_workspace_floats": (_Z, [_L]),
+    "nf_paper_saved_floats": (_Z, [_L]),
+    "nf_paper_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "nf_paper_packed_bwd_floats": (_Z, []),
+    "nf_paper_pack_bwd": (C.c_int, [_P, _P, _P]),
     "nf_paper_grad_floats": (_Z, []),
-    "nf_paper_unpack_grads": (C.c_int, [_P, _P, _P, _P]),
+    "nf_paper_bwd_workspace_floats": (_Z, [_L]),
+    "nf_paper_mlp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_volume_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "nf_volume_render_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "nf_sample_pdf": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
@@ -42,7 +45,7 @@ _PROTOTYPES = {
     "nf_sort_rows": (C.c_int, [_P, _L, _I, _P, _P]),
 }
 # entry points that later ABI revisions add; absent symbols only fail when called
-_OPTIONAL = {"nf_paper_mlp_bwd", "nf_paper_bwd_workspace_floats", "nf_paper_grad_floats", "nf_paper_unpack_grads"}
+_OPTIONAL = set()
 
 
 def lib_path() -> str:

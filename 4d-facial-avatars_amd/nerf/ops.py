@@ -108,6 +108,20 @@ class PaperWeights:
         self.packed_t = None            # transposed image for the backward chain (lazily built)
         self._versions_t = None
 
+    def get_t(self) -> torch.Tensor:
+        """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
+        sig = self._signature()
+        if self.packed_t is None or sig != self._versions_t:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed_t is None or self.packed_t.device != dev:
+                self.packed_t = torch.empty(lib.nf_paper_packed_bwd_floats(), dtype=torch.float32, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack_bwd(arr, H.ptr(self.packed_t), H.stream_ptr(dev)), "nf_paper_pack_bwd")
+            self._versions_t = sig
+        return self.packed_t
+
     def _signature(self):
         return tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
 
@@ -146,6 +160,47 @@ def paper_mlp_fwd(packed, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
         H.check(H.lib().nf_paper_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
                                          n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd")
     return raw
+
+
+def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None):
+    """Training forward: returns (raw, (saved,)) where `saved` holds every layer output for the backward."""
+    dev = H.require_device(packed, cond, ro, rd, z, rd_view)
+    n_rays, n_samples = z.shape
+    lib = H.lib()
+    raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    saved = torch.empty(lib.nf_paper_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(lib.nf_paper_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                           n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_paper_mlp_fwd_train")
+    return raw, (saved,)
+
+
+_PARAM_NUMEL = None
+
+
+def paper_mlp_bwd(model, packed, cond, ro, rd, z, rd_view, expr, latent, d_raw, saved):
+    """d_raw (n_rays, n_samples, 4) -> ([26 parameter gradients in state_dict order], d_latent (32)).
+    layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3)."""
+    global _PARAM_NUMEL
+    (saved_t,) = saved
+    d_raw = _c(d_raw)
+    dev = H.require_device(packed, cond, saved_t, d_raw)
+    lib = H.lib()
+    n_rays, n_samples = z.shape
+    packed_t = model.hip_weights().get_t()
+    ws_floats = lib.nf_paper_bwd_workspace_floats(n_rays * n_samples)
+    ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+    flat = torch.empty(lib.nf_paper_grad_floats(), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(lib.nf_paper_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
+                                     n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd")
+    params = model.hip_param_list()
+    grads, off = [], 0
+    for i, p in enumerate(params):
+        n = p.numel()
+        grads.append(None if i in (22, 23) else flat[off:off + n].view(p.shape))
+        off += n
+    return grads, flat[off:off + 32]
 
 
 # ---------------------------------------------------------------------------------------- K5

@@ -71,6 +71,23 @@ int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, co
                      const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                      nf_stream_t stream);
 
+/* ---- K4 training path ---------------------------------------------------------------------------------
+ * The reference trains through autograd (train_transformed_rays.py:389); here the forward saves every layer
+ * output (`saved`, nf_paper_saved_floats(n_points) floats) and nf_paper_mlp_bwd turns d_raw (n_points,4)
+ * into the gradients of all 26 parameters (reference layout, state_dict order, flattened) followed by the
+ * 32 latent-code gradients: nf_paper_grad_floats() floats in total.  layers_dir.3 gets zeros (Quirk Q3).   */
+size_t nf_paper_saved_floats(int64_t n_points);
+int nf_paper_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd,
+                           const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                           float* saved, nf_stream_t stream);
+size_t nf_paper_packed_bwd_floats(void);  /* transposed fragment image used by the backward chain        */
+int nf_paper_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream);
+size_t nf_paper_grad_floats(void);
+size_t nf_paper_bwd_workspace_floats(int64_t n_points);
+int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved,
+                     const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
+                     size_t workspace_floats, float* grads, nf_stream_t stream);
+
 /* ---- K5: volume integrator -- replaces volume_render_radiance_field (V:7-75) + cumprod_exclusive
  *      (H:44-65) + the background overwrite of T:95-96 ----------------------------------------------- */
 /* bg (n_rays,3) or NULL; noise (n_rays,S) already scaled by noise_std, or NULL.  Outputs: rgb (R,3),

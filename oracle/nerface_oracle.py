@@ -108,26 +108,41 @@ def _lin(x, p, name):
 
 
 def paper_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor,
-              relu_mask_hook=None) -> torch.Tensor:
+              masks: Optional[Sequence[torch.Tensor]] = None, acts: Optional[list] = None) -> torch.Tensor:
     """ConditionalBlendshapePaperNeRFModel.forward (M:236-261): (P, 87) -> (P, 4) = [rgb_raw, sigma_raw].
 
     x0 = [pe_xyz(63) | expr*1/3 (76) | latent (32)]; 3x(Linear+ReLU); skip-concat [x0 | h] at layer 3;
     3x(Linear+ReLU); feat = fc_feat(h) (no activation); sigma = fc_alpha(feat) (Q2: reads feat);
     [feat | pe_dir(24)] -> layers_dir.0..2 (+ReLU) (Q3: layers_dir.3 unused); rgb = fc_rgb.
+
+    Test hooks: `masks` (9 boolean tensors) replaces each ReLU by a multiplication with a given mask, so that a
+    gradient comparison is not polluted by units whose pre-activation sits within rounding of zero; `acts`
+    (a list) collects the 9 post-ReLU activations and feat.
     """
     n = x87.shape[0]
     xyz, dirs = x87[:, :63], x87[:, 63:]
     e = (expr * 1 / 3).reshape(1, -1).repeat(n, 1)              # true division, M:241
     l = latent.reshape(1, -1).repeat(n, 1)
     x0 = torch.cat((xyz, e, l), dim=1)
+    k = [0]
+
+    def act(v):
+        out = torch.relu(v) if masks is None else v * masks[k[0]].to(v.dtype)
+        k[0] += 1
+        if acts is not None:
+            acts.append(out)
+        return out
+
     h = x0
     for i in range(6):
-        h = torch.relu(_lin(torch.cat((x0, h), dim=-1) if i == 3 else h, p, f"layers_xyz.{i}"))
+        h = act(_lin(torch.cat((x0, h), dim=-1) if i == 3 else h, p, f"layers_xyz.{i}"))
     feat = _lin(h, p, "fc_feat")
+    if acts is not None:
+        acts.append(feat)
     sigma = _lin(feat, p, "fc_alpha")
-    h = torch.relu(_lin(torch.cat((feat, dirs), dim=-1), p, "layers_dir.0"))
-    h = torch.relu(_lin(h, p, "layers_dir.1"))
-    h = torch.relu(_lin(h, p, "layers_dir.2"))
+    h = act(_lin(torch.cat((feat, dirs), dim=-1), p, "layers_dir.0"))
+    h = act(_lin(h, p, "layers_dir.1"))
+    h = act(_lin(h, p, "layers_dir.2"))
     rgb = _lin(h, p, "fc_rgb")
     return torch.cat((rgb, sigma), dim=-1)
 

@@ -1,0 +1,178 @@
+"""Gradient parity of the HIP training path against autograd on the CPU oracle (and the reference's own autograd
+via the golden fixture).  GPU only.  Gate: relative L2 error <= 1e-4 per parameter tensor."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import nerface_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize("n_rays,s,bgflag,noisy", [(6, 64, True, True), (5, 192, True, False), (4, 7, False, False), (3, 130, True, True)])
+def test_volume_render_bwd(hip_lib, gpu, n_rays, s, bgflag, noisy):
+    from nerf import ops
+    g = torch.Generator().manual_seed(21)
+    raw = (torch.randn((n_rays, s, 4), generator=g) * 2.0).double()
+    raw[..., 3] = raw[..., 3] * 8
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0].double()
+    rd = torch.randn((n_rays, 3), generator=g).double()
+    bg = torch.rand((n_rays, 3), generator=g).double() if bgflag else None
+    noise = (torch.randn((n_rays, s), generator=g) * 0.1).double() if noisy else None
+    d_rgb = torch.randn((n_rays, 3), generator=g).double()
+    raw_l = raw.clone().requires_grad_(True)
+    raw_in = raw_l
+    if bg is not None:                                  # T:95-96: the overwrite kills the gradient of the last colour
+        raw_in = torch.cat((raw_l[:, :-1], torch.cat((bg[:, None, :], raw_l[:, -1:, 3:]), dim=-1)), dim=1)
+    rgb, *_ = O.volume_render(raw_in, z, rd, noise, has_background=bgflag)
+    rgb.backward(d_rgb)
+    f = lambda t: None if t is None else t.float().to(gpu).contiguous()
+    d_raw = ops.volume_render_bwd(f(raw), f(z), f(rd), f(noise), f(bg), f(d_rgb)).cpu()
+    err = rel_l2(d_raw, raw_l.grad)
+    print("volume_render_bwd rel L2", err)
+    assert err < 2e-5
+
+
+# sections of the saved-activation buffer (csrc/nf_mlp_layout.h: nfl::S_*): (offset, width)
+SAVED = dict(pe=(0, 64), h0=(64, 256), h1=(320, 256), h2=(576, 256), h3=(832, 256), h4=(1088, 256), h5=(1344, 256),
+             feat=(1600, 256), d0=(1856, 128), d1=(1984, 128), d2=(2112, 128), dirf=(2240, 16))
+RELU_ORDER = ["h0", "h1", "h2", "h3", "h4", "h5", "d0", "d1", "d2"]
+
+
+def saved_section(saved, name, n_points):
+    off, w = SAVED[name]
+    return saved[off * n_points:(off + w) * n_points].view(n_points, w)
+
+
+def _oracle_mlp_grads(p, ro, rd, z, expr, latent, d_raw, masks=None, dtype=torch.float64):
+    pp = {k: v.to(dtype).clone().requires_grad_(True) for k, v in p.items()}
+    lat = latent.to(dtype).clone().requires_grad_(True)
+    x = O.encode_points(ro.to(dtype), rd.to(dtype), z.to(dtype), O.NEAR, O.FAR)
+    acts = []
+    out = O.paper_mlp(pp, x, expr.to(dtype), lat, masks=masks, acts=acts)
+    out.backward(d_raw.reshape(-1, 4).to(dtype))
+    return pp, lat, acts
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
+def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
+    import nerf
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    g = torch.Generator().manual_seed(13)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 9, n_rays, 13)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    d_raw = torch.randn((n_rays, s, 4), generator=g)
+    p = c["p_fine"]
+    m = U.make_model(nerf, p, gpu)
+    pk = m.hip_weights().get()
+    cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    raw_t, saved = ops.paper_mlp_fwd_train(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
+    raw_e = ops.paper_mlp_fwd(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
+    assert torch.equal(raw_t, raw_e)                       # training forward == eval forward, bit for bit
+    # saved activations against the oracle (spot check: fc_feat output and PE slots that hold raw xyz)
+    grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, None, None, z.to(gpu), None, None, None, d_raw.to(gpu), saved)
+    # ReLU masks as the HIP forward saw them: the oracle's backward is evaluated with the same masks so that the
+    # comparison measures the backward arithmetic, not the handful of units whose pre-activation rounds across 0
+    n_pts = n_rays * s
+    sv = saved[0].cpu()
+    masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
+    pp, lat, acts = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=masks)
+    _, _, acts_free = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=None)
+    order = RELU_ORDER[:6] + ["feat"] + RELU_ORDER[6:]
+    flips = 0
+    for name, a_free in zip(order, acts_free):
+        got = saved_section(sv, name, n_pts)
+        assert (got.double() - a_free).abs().max() < 1e-4 * (1 + float(a_free.detach().abs().max())), name     # saved activations
+        if name != "feat":
+            flips += int(((got > 0) != (a_free > 0)).sum())
+    print(f"ReLU mask flips vs fp64 oracle: {flips} of {sum(mk.numel() for mk in masks)}")
+    assert flips <= 1e-5 * sum(mk.numel() for mk in masks) + 2
+    worst = 0.0
+    for k, gh in zip(ops.PAPER_KEYS, grads):
+        go = pp[k].grad
+        if k.startswith("layers_dir.3"):
+            assert gh is None and (go is None or float(go.abs().max()) == 0.0)
+            continue
+        e = rel_l2(gh.cpu(), go)
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)
+    e = rel_l2(g_lat.cpu(), lat.grad)
+    print(f"mlp bwd ({n_rays}x{s}): worst param rel L2 {worst:.2e}, latent {e:.2e}")
+    assert e < 1e-4
+
+
+def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
+    """Full training step (coarse+fine, noise, perturb, latent regulariser) through run_one_iter_of_nerf + autograd."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    out, mc, mf, latent = U.run_product(nerf, c, gpu, mode="train", grad=True)
+    loss = O.train_loss(out[0], out[3], c["tgt"].to(gpu), latent)
+    loss.backward()
+    gold = np.load(os.path.join(GOLD, "train_rand_64_64_grads.npz"))
+    assert abs(float(loss) - float(gold["loss"])) < 2e-6
+    # oracle autograd in fp64 on identical inputs
+    pc = {k: v.double().clone().requires_grad_(True) for k, v in c["p_coarse"].items()}
+    pf = {k: v.double().clone().requires_grad_(True) for k, v in c["p_fine"].items()}
+    lat = c["latent"].double().clone().requires_grad_(True)
+    d = lambda t: None if t is None else t.double()
+    o = O.render_rays(pc, pf, d(c["ro"]), d(c["rd"]), d(c["expr"]), lat, d(c["bg"]), O.NEAR, O.FAR, 64, 64, t_rand=d(c["t_rand"]),
+                      noise_c=d(c["noise_c"]), u=d(c["u"]), noise_f=d(c["noise_f"]))
+    O.train_loss(o[0], o[3], d(c["tgt"]), lat).backward()
+    worst = 0.0
+    for tag, m, po in (("coarse", mc, pc), ("fine", mf, pf)):
+        for k, v in m.named_parameters():
+            if k.startswith("layers_dir.3"):
+                assert v.grad is None                                     # Q3, and `none:` entries of the fixture
+                assert f"none:{tag}.{k}" in gold.files
+                continue
+            e = rel_l2(v.grad.cpu(), po[k].grad)
+            worst = max(worst, e)
+            # End to end, fp32 vs fp64 differ by the odd ReLU unit (MLP or the density ReLU of V:52) whose
+            # pre-activation rounds across zero -- each flip moves a gradient tensor by O(1/sqrt(#points)) -- and the fine
+            # pass inherits the resampled-depth sensitivity (test_gpu_e2e.TOL).  The 1e-4 gate on the backward arithmetic
+            # itself is enforced mask-consistently in test_paper_mlp_bwd / test_volume_render_bwd above.
+            assert e < 3e-3, (tag, k, e)
+            want = float(gold[f"norm:{tag}.{k}"])
+            assert abs(float(v.grad.double().norm()) - want) <= 2e-3 * want + 1e-9, (tag, k)
+    e_lat = rel_l2(latent.grad.cpu(), lat.grad)
+    e_ref = rel_l2(latent.grad.cpu(), torch.from_numpy(gold["latent"]))
+    print(f"train step: worst param rel L2 {worst:.2e}; latent vs oracle(fp64) {e_lat:.2e}, vs reference autograd {e_ref:.2e}")
+    assert e_lat < 2e-3 and e_ref < 2e-3
+
+
+def test_adam_step_moves_live_parameters(hip_lib, gpu):
+    """The trainer's loop (TR:389-392): backward, Adam over [coarse, fine, latent table], zero_grad; the cached weight
+    image must follow the in-place update (version counters) and the gradient must land in the latent ROW."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+    table = torch.zeros((5, 32), device=gpu, requires_grad=True)
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()) + [table], lr=1e-3)
+    o = U.make_options(nerf, 64, 64, True, 0.1)
+    ex, ed = U.encoders(nerf)
+    losses = []
+    for it in range(3):
+        torch.manual_seed(100 + it)
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), o, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                        background_prior=c["bg"].to(gpu), latent_code=table[2])
+        loss = O.train_loss(out[0], out[3], c["tgt"].to(gpu), table[2])
+        loss.backward()
+        if it == 0:
+            assert float(table.grad[2].abs().sum()) > 0 and float(table.grad[[0, 1, 3, 4]].abs().sum()) == 0.0
+            assert mc.layers_dir[3].weight.grad is None
+        opt.step()
+        opt.zero_grad()
+        losses.append(float(loss))
+    assert all(np.isfinite(losses))
+    assert losses[-1] < losses[0]                    # 3 Adam steps on the same rays/target reduce the loss
