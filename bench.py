@@ -99,12 +99,91 @@ def cpu_baseline(n_rays=1536):
             "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s"}
 
 
+def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
+    """configs[2] / configs[4]: the trainer's iteration (TR:289-400) on synthetic data -- full-frame ray bundle, 2048 random
+    rays, run_one_iter_of_nerf(mode='train') with the shipped training settings (64+64, chunksize 2048, perturb, noise
+    0.1), coarse+fine MSE + latent regulariser, backward, (N>1: one flat RCCL all-reduce), Adam over
+    [coarse, fine, latent table]."""
+    from nerf import distributed as D
+    n_rays, n_train = 2048, 1000
+    mode = dict(num_coarse=64, num_fine=64, chunksize=2048, perturb=True, lindisp=False, radiance_field_noise_std=0.1,
+                white_background=False)
+    opt = nerf.CfgNode(dict(nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode)),
+                            dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
+    enc_xyz = nerf.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = nerf.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    model_c.train()
+    model_f.train()
+    latent_codes = torch.zeros(n_train, 32, device=dev).requires_grad_(True)
+    params = list(model_c.parameters()) + list(model_f.parameters()) + [latent_codes]
+    D.broadcast_parameters(params)
+    optim = torch.optim.Adam(params, lr=5e-4)
+    reducer = D.GradientAllReducer(params)
+    g = torch.Generator().manual_seed(7)
+    background = torch.rand((H, W, 3), generator=g).to(dev).view(-1, 3)
+    target = torch.rand((H, W, 3), generator=g).to(dev).view(-1, 3)
+    torch.manual_seed(D.rank_seed(1234))
+    n_it = args.steps + args.warmup
+    frame_ids = torch.randint(0, n_train, (n_it,)).tolist()
+    poses = [frame_pose(f).to(dev) for f in frame_ids]
+    exprs = [(0.5 * torch.randn(76)).to(dev) for _ in frame_ids]
+
+    def step(i):
+        ro, rd = nerf.get_ray_bundle(H, W, INTRINSICS, poses[i])
+        idx = torch.randperm(H * W, device=dev)[:n_rays]
+        latent = latent_codes[frame_ids[i]]
+        out = nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro.view(-1, 3)[idx], rd.view(-1, 3)[idx], opt,
+                                        mode="train", encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                        expressions=exprs[i], background_prior=background[idx], latent_code=latent)
+        tgt = target[idx]
+        loss = (torch.nn.functional.mse_loss(out[0], tgt) + torch.nn.functional.mse_loss(out[3], tgt)
+                + 10 * 0.0005 * torch.norm(latent))
+        loss.backward()
+        reducer.reduce()
+        optim.step()
+        optim.zero_grad()
+        return loss
+
+    for i in range(args.warmup):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.warmup, n_it):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert bool(torch.isfinite(loss))
+    if rank == 0:
+        print(json.dumps({
+            "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
+            "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[2]: paper-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
+                                   "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
+                       "rays_per_step": n_rays * world, "parallelism": f"dp{world}"}}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--mode", choices=["eval", "train"], default="eval",
+                    help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=1536)
     args = ap.parse_args()
 
@@ -130,6 +209,8 @@ def main():
     from nerf import ops
 
     model_c, model_f = synth_params(0, dev), synth_params(1, dev)
+    if args.mode == "train":
+        return bench_train(args, nerf, model_c, model_f, dev, rank, world, dist)
     opt = options(nerf)
     enc_xyz = nerf.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
     enc_dir = nerf.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
