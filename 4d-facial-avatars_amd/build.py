@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libnerface_hip.so")
-SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip"]
+SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_mlp_bf16.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 
@@ -49,7 +49,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         objs.append(obj)
         procs.append((s, subprocess.Popen([cc, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
-        out, _ = p.communicate()
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            raise RuntimeError(f"hipcc timed out on {s}")
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
         if verbose and out.strip():

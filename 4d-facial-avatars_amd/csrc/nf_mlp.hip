@@ -131,7 +131,8 @@ static int nf_get_table(uint32_t** out) {
 }
 
 extern "C" size_t nf_paper_packed_floats(void) { return (size_t)nfl::PACKED_FLOATS; }
-extern "C" size_t nf_paper_cond_floats(void) { return (size_t)nfl::COND_FLOATS; }
+// 2332 floats are written; the buffer is padded to 10 KiB so that the bf16 kernel can DMA it into LDS in whole KiB blocks
+extern "C" size_t nf_paper_cond_floats(void) { return 2560; }
 
 // Host-side copy of the gather table (for layout tests without a GPU): code = tensor_id << 24 | offset.
 extern "C" int nf_paper_gather_table(uint32_t* out, size_t n) {

@@ -11,7 +11,8 @@ import threading
 
 import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libnerface_hip.so")
+_LIB_PATH = os.environ.get("NERFACE_HIP_LIB") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib",
+                                                             "libnerface_hip.so")
 _lib = None
 _lock = threading.Lock()
 
@@ -31,6 +32,9 @@ _PROTOTYPES = {
     "nf_paper_pack": (C.c_int, [_P, _P, _P]),
     "nf_paper_condition": (C.c_int, [_P, _P, _P, _F, _F, _P, _P]),
     "nf_paper_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_paper_packed_bf16_bytes": (_Z, []),
+    "nf_paper_pack_bf16": (C.c_int, [_P, _P, _P]),
+    "nf_paper_mlp_fwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "nf_paper_saved_floats": (_Z, [_L]),
     "nf_paper_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_paper_packed_bwd_floats": (_Z, []),

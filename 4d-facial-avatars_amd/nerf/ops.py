@@ -6,6 +6,7 @@ non-zero return codes into RuntimeError.  No numerical work happens in Python.
 from __future__ import annotations
 
 import ctypes as C
+import os
 import weakref
 from typing import Optional, Sequence
 
@@ -20,6 +21,24 @@ PAPER_KEYS = (
     + [f"layers_dir.{i}.{p}" for i in range(4) for p in ("weight", "bias")]
     + [f"fc_rgb.{p}" for p in ("weight", "bias")]
 )
+
+
+# Arithmetic of the inference-time MLP GEMMs: "f32" = exact-f32 MFMA (bit-for-bit the training forward);
+# "bf16x3" = split-bf16, three bf16 MFMAs per product with f32 accumulation (~2^-16 relative per layer, 3x faster).
+# Training (anything that needs gradients) always runs the exact-f32 kernels.
+_VALID_PRECISIONS = ("f32", "bf16x3")
+_mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
+
+
+def set_mlp_precision(mode: str) -> None:
+    global _mlp_precision
+    if mode not in _VALID_PRECISIONS:
+        raise ValueError(f"precision must be one of {_VALID_PRECISIONS}")
+    _mlp_precision = mode
+
+
+def get_mlp_precision() -> str:
+    return _mlp_precision
 
 
 def _c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
@@ -107,6 +126,8 @@ class PaperWeights:
         self.packed = None
         self.packed_t = None            # transposed image for the backward chain (lazily built)
         self._versions_t = None
+        self.packed_b = None            # (hi, lo) bf16 stream for the split-bf16 forward (lazily built)
+        self._versions_b = None
 
     def get_t(self) -> torch.Tensor:
         """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
@@ -121,6 +142,19 @@ class PaperWeights:
                 H.check(lib.nf_paper_pack_bwd(arr, H.ptr(self.packed_t), H.stream_ptr(dev)), "nf_paper_pack_bwd")
             self._versions_t = sig
         return self.packed_t
+
+    def get_bf16(self) -> torch.Tensor:
+        sig = self._signature()
+        if self.packed_b is None or sig != self._versions_b:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed_b is None or self.packed_b.device != dev:
+                self.packed_b = torch.empty(lib.nf_paper_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack_bf16(arr, H.ptr(self.packed_b), H.stream_ptr(dev)), "nf_paper_pack_bf16")
+            self._versions_b = sig
+        return self.packed_b
 
     def _signature(self):
         return tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
@@ -159,6 +193,17 @@ def paper_mlp_fwd(packed, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
     with torch.cuda.device(dev):
         H.check(H.lib().nf_paper_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
                                          n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd")
+    return raw
+
+
+def paper_mlp_fwd_bf16(packed_b, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
+    """Split-bf16 (3 x bf16 MFMA, f32 accumulate) forward; same outputs as paper_mlp_fwd to ~1e-5 relative."""
+    dev = H.require_device(cond, ro, rd, z, rd_view)
+    n_rays, n_samples = z.shape
+    raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_paper_mlp_fwd_bf16(H.ptr(packed_b), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                              n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd_bf16")
     return raw
 
 

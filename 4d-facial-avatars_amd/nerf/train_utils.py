@@ -50,11 +50,14 @@ class _RenderChunk(torch.autograd.Function):
         dev = ro.device
         n_rays = ro.shape[0]
 
+        split = (not need_grad) and ops.get_mlp_precision() == "bf16x3"
         pk_c = model_c.hip_weights().get()
         cond_c = ops.paper_condition(pk_c, expr, latent, near, far)
         z_c = ops.sample_coarse(n_rays, nc, near, far, dev, t_rand)
         if need_grad:
             raw_c, saved_c = ops.paper_mlp_fwd_train(pk_c, cond_c, ro, rd, z_c, rd_view)
+        elif split:
+            raw_c, saved_c = ops.paper_mlp_fwd_bf16(model_c.hip_weights().get_bf16(), cond_c, ro, rd, z_c, rd_view), None
         else:
             raw_c, saved_c = ops.paper_mlp_fwd(pk_c, cond_c, ro, rd, z_c, rd_view), None
         rgb_c, disp_c, acc_c, w_c = ops.volume_render_fwd(raw_c, z_c, rd, noise_c, bg, white)
@@ -66,6 +69,8 @@ class _RenderChunk(torch.autograd.Function):
             cond_f = ops.paper_condition(pk_f, expr, latent, near, far)
             if need_grad:
                 raw_f, saved_f = ops.paper_mlp_fwd_train(pk_f, cond_f, ro, rd, z_f, rd_view)
+            elif split:
+                raw_f, saved_f = ops.paper_mlp_fwd_bf16(model_f.hip_weights().get_bf16(), cond_f, ro, rd, z_f, rd_view), None
             else:
                 raw_f, saved_f = ops.paper_mlp_fwd(pk_f, cond_f, ro, rd, z_f, rd_view), None
             rgb_f, disp_f, acc_f, w_f = ops.volume_render_fwd(raw_f, z_f, rd, noise_f, bg, white)

@@ -71,6 +71,15 @@ int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, co
                      const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                      nf_stream_t stream);
 
+/* ---- K4, split-bf16 variant (eval): every GEMM as 3 bf16 MFMAs (W_hi x_hi + W_hi x_lo + W_lo x_hi) with f32
+ * accumulation -- ~2^-16 relative per layer instead of 2^-24, 3x the throughput of the exact-f32 matrix rate.
+ * Same arguments/semantics as nf_paper_mlp_fwd; `cond` is the same table (from the f32 image).              */
+size_t nf_paper_packed_bf16_bytes(void);
+int nf_paper_pack_bf16(const float* const* params, void* packed_bf16, nf_stream_t stream);
+int nf_paper_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
+                          const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                          nf_stream_t stream);
+
 /* ---- K4 training path ---------------------------------------------------------------------------------
  * The reference trains through autograd (train_transformed_rays.py:389); here the forward saves every layer
  * output (`saved`, nf_paper_saved_floats(n_points) floats) and nf_paper_mlp_bwd turns d_raw (n_points,4)

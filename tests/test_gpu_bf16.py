@@ -1,0 +1,52 @@
+"""Split-bf16 (3 x bf16 MFMA) forward: parity against the fp64 oracle / the exact-f32 kernel.  GPU only."""
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import nerface_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (5, 192), (1, 1), (40, 192)])
+def test_bf16x3_mlp_vs_oracle(hip_lib, gpu, n_rays, s):
+    import nerf
+    from nerf import ops
+    c = C.build_case("eval_det_64_128")
+    g = torch.Generator().manual_seed(5)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 3, n_rays, 5)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    p = c["p_fine"]
+    m = U.make_model(nerf, p, gpu)
+    hw = m.hip_weights()
+    cond = ops.paper_condition(hw.get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    raw_b = ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu)).cpu()
+    raw_f = ops.paper_mlp_fwd(hw.get(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu)).cpu()
+    p64 = {k: v.double() for k, v in p.items()}
+    ref = O.paper_mlp(p64, O.encode_points(ro.double(), rd.double(), z.double(), O.NEAR, O.FAR), c["expr"].double(),
+                      c["latent"].double()).reshape(n_rays, s, 4)
+    scale = ref.abs().amax(dim=(0, 1))
+    eb = (raw_b.double() - ref).abs().amax(dim=(0, 1))
+    ef = (raw_f.double() - ref).abs().amax(dim=(0, 1))
+    print(f"bf16x3 max err {eb.tolist()}  f32 max err {ef.tolist()}  scale {scale.tolist()}")
+    assert torch.all(eb <= 3e-4 * scale + 1e-5)
+
+
+def test_bf16x3_psnr_gate(hip_lib, gpu):
+    """The north-star gate with the split-bf16 inference kernel: |PSNR(ours,tgt) - PSNR(reference,tgt)| <= 1e-4 dB."""
+    import nerf
+    c = C.build_case("eval_det_64_128")
+    ro, rd, bg, tgt, idx = C.ray_subset(512, 512, c["frame"], 1024, seed=99)
+    c.update(n_rays=1024, ro=ro, rd=rd, bg=bg, tgt=tgt, idx=idx)
+    ref = C.run_oracle(c)
+    nerf.set_mlp_precision("bf16x3")
+    try:
+        out, *_ = U.run_product(nerf, c, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+    for k, name in ((0, "rgb_coarse"), (3, "rgb_fine")):
+        p_ref, p_our = O.psnr(ref[k], tgt), O.psnr(out[k].cpu(), tgt)
+        print(f"bf16x3 {name}: PSNR ref {p_ref:.6f} ours {p_our:.6f} |d|={abs(p_ref - p_our):.2e} dB, self-PSNR {O.psnr(out[k].cpu(), ref[k]):.1f} dB,"
+              f" max|d rgb|={float((out[k].cpu() - ref[k]).abs().max()):.2e}")
+        assert abs(p_ref - p_our) <= 1e-4
