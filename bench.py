@@ -41,6 +41,8 @@ N_COARSE, N_FINE = 64, 128
 CHUNK = 65536
 FLOP_PER_POINT = 1_100_032            # algorithmic forward FLOPs of the paper MLP per point
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+BF16X3_EXEC_FLOP_PER_POINT = 3012 * 32768 / 32   # executed MFMA FLOPs per point of the split-bf16 kernel (3012 MFMAs / 32 points)
 INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
 NEAR, FAR = 0.2, 0.8
 
@@ -182,6 +184,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
+                    help="inference GEMM arithmetic: bf16x3 = split-bf16 (3 bf16 MFMAs per product, f32 accumulate; passes the "
+                         "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=1536)
@@ -207,6 +212,7 @@ def main():
         dist.barrier()
     import nerf
     from nerf import ops
+    nerf.set_mlp_precision(args.precision)
 
     model_c, model_f = synth_params(0, dev), synth_params(1, dev)
     if args.mode == "train":
@@ -256,10 +262,12 @@ def main():
     line = {
         "metric": "rays/sec at 512x512, 64 coarse + 128 fine samples", "value": rays_total / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32", "data": "synthetic",
         "config": {"workload": "configs[1]: paper-model eval forward, 512x512 frame, 64+128 samples, chunksize 65536, "
                                "perturb on, expression+latent conditioned, background prior; frames sharded over GPUs",
-                   "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}"},
+                   "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}",
+                   "mlp_precision": args.precision},
     }
 
     if rank == 0:
@@ -270,29 +278,46 @@ def main():
         ro, rd = nerf.get_ray_bundle(H, W, INTRINSICS, poses[0])
         ro, rd = ro.view(-1, 3)[:CHUNK].contiguous(), rd.view(-1, 3)[:CHUNK].contiguous()
         z = torch.sort(torch.rand((CHUNK, S), device=dev) * (FAR - NEAR) + NEAR, dim=-1)[0].contiguous()
-        for _ in range(2):
-            ops.paper_mlp_fwd(pk, cond, ro, rd, z)
-        n_launch = 8
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]   # recorded on the launch stream
-        ev[0].record()
-        for k in range(n_launch):
-            ops.paper_mlp_fwd(pk, cond, ro, rd, z)
-            ev[k + 1].record()
-        torch.cuda.synchronize()
-        avg_ms = sum(ev[k].elapsed_time(ev[k + 1]) for k in range(n_launch)) / n_launch
+        pk_b = model_f.hip_weights().get_bf16()
+
+        def timed(fn, n_launch=8):
+            for _ in range(2):
+                fn()
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(n_launch + 1)]   # recorded on the launch stream
+            ev[0].record()
+            for k in range(n_launch):
+                fn()
+                ev[k + 1].record()
+            torch.cuda.synchronize()
+            return sum(ev[k].elapsed_time(ev[k + 1]) for k in range(n_launch)) / n_launch
+
         flops = float(CHUNK) * S * FLOP_PER_POINT
-        achieved = flops / (avg_ms * 1e-3) / 1e12
+        ms_f32 = timed(lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z))
+        ms_b16 = timed(lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z))
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "mlp_fwd_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_" + args.precision)
             except Exception:
                 traffic = None
-        line["roofline"] = {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2> (65536 rays x 192 samples per launch)",
-                            "achieved": achieved, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": achieved / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": avg_ms,
-                            "algorithmic_flops_per_launch": flops, "traffic": traffic}
+        f32_obj = {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2,false> (65536 rays x 192 samples per launch)",
+                   "achieved": flops / (ms_f32 * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                   "frac": flops / (ms_f32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms_f32,
+                   "algorithmic_flops_per_launch": flops}
+        if args.precision == "bf16x3":
+            ach = flops / (ms_b16 * 1e-3) / 1e12
+            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms_b16 * 1e-3) / 1e12
+            line["roofline"] = {"bound": "mfma", "kernel": "k_paper_mlp_fwd_bf16 (65536 rays x 192 samples per launch)",
+                                "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                                "avg_launch_ms": ms_b16, "algorithmic_flops_per_launch": flops, "traffic": traffic,
+                                "executed_tflops": exe, "frac_executed": exe / PEAK_BF16_MFMA_TFLOPS,
+                                "note": "achieved counts ALGORITHMIC f32 FLOPs (1,100,032/point); each costs 3 bf16 MFMA FLOPs in the "
+                                        "split scheme, so frac cannot exceed 1/3; executed_* counts the issued MFMA FLOPs"}
+            line["roofline_exact_f32_kernel"] = f32_obj
+        else:
+            f32_obj["traffic"] = traffic
+            line["roofline"] = f32_obj
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
         print(json.dumps(line), flush=True)

@@ -50,3 +50,53 @@ def test_bf16x3_psnr_gate(hip_lib, gpu):
         print(f"bf16x3 {name}: PSNR ref {p_ref:.6f} ours {p_our:.6f} |d|={abs(p_ref - p_our):.2e} dB, self-PSNR {O.psnr(out[k].cpu(), ref[k]):.1f} dB,"
               f" max|d rgb|={float((out[k].cpu() - ref[k]).abs().max()):.2e}")
         assert abs(p_ref - p_our) <= 1e-4
+
+
+# coarse outputs: split-bf16 rounding (~2^-16 per layer) through one 11-layer MLP; fine outputs: plus the resampled-depth
+# sensitivity shared with the exact-f32 path (tests/test_gpu_e2e.py: TOL)
+TOL_B = dict(rgb_c=3e-5, rgb_f=5e-4, acc_c=1e-5, acc_f=1e-5, w_last=5e-4, disp_c=1e-4, disp_f=2e-3)
+
+
+@pytest.mark.parametrize("name", list(C.CASES))
+def test_bf16x3_against_golden_reference(hip_lib, gpu, name):
+    import os
+    import numpy as np
+    import nerf
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    c = C.build_case(name)
+    nerf.set_mlp_precision("bf16x3")
+    try:
+        out, *_ = U.run_product(nerf, c, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+    for n, t in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"], out):
+        if n not in gold.files:
+            assert t is None
+            continue
+        d = np.abs(t.cpu().numpy() - gold[n])
+        print(f"[bf16x3 {name}] {n}: max|d|={d.max():.3e}")
+        assert d.max() <= TOL_B[n], (n, d.max())
+
+
+@pytest.mark.parametrize("frame,seed", [(11, 3), (57, 4), (90, 5)])
+def test_bf16x3_psnr_gate_more_frames(hip_lib, gpu, frame, seed):
+    """The 1e-4 dB gate on other frames / weight seeds / stochastic sampling (perturb on, injected draws)."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    n = 768
+    ro, rd, bg, tgt, idx = C.ray_subset(512, 512, frame, n, seed=seed)
+    expr, latent = O.frame_conditioning(frame)
+    t_rand, noise_c, u, noise_f = C.randoms(n, 64, 128, seed=seed)
+    c.update(frame=frame, n_rays=n, n_coarse=64, n_fine=128, ro=ro, rd=rd, bg=bg, tgt=tgt, idx=idx, expr=expr, latent=latent,
+             stochastic=True, noise_std=0.0, t_rand=t_rand, u=u, noise_c=None, noise_f=None,
+             p_coarse=O.init_paper_params(10 + seed), p_fine=O.init_paper_params(20 + seed))
+    ref = C.run_oracle(c)
+    nerf.set_mlp_precision("bf16x3")
+    try:
+        out, *_ = U.run_product(nerf, c, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+    for k in (0, 3):
+        p_ref, p_our = O.psnr(ref[k], tgt), O.psnr(out[k].cpu(), tgt)
+        print(f"frame {frame} output {k}: |dPSNR| = {abs(p_ref - p_our):.2e} dB, self-PSNR {O.psnr(out[k].cpu(), ref[k]):.1f} dB")
+        assert abs(p_ref - p_our) <= 1e-4
