@@ -1,0 +1,68 @@
+"""Shared plumbing of the launchers: config, models, background, distributed bring-up."""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+import yaml
+
+PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if PKG not in sys.path:
+    sys.path.insert(0, PKG)
+
+import nerf  # noqa: E402
+from nerf import distributed as D  # noqa: E402
+
+
+def init_distributed():
+    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("the MI355X `nerf` package needs a ROCm device")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=dev)      # nccl == RCCL on ROCm
+    return rank, world, dev
+
+
+def load_config(path: str):
+    with open(path, "r") as f:
+        return nerf.CfgNode(yaml.load(f, Loader=yaml.FullLoader))
+
+
+def build_models(cfg, device):
+    """getattr(models, cfg.models.*.type)(...) exactly as the reference scripts construct them (TR:100-124)."""
+    def make(m):
+        return getattr(nerf.models, m.type)(
+            num_encoding_fn_xyz=m.num_encoding_fn_xyz, num_encoding_fn_dir=m.num_encoding_fn_dir,
+            include_input_xyz=m.include_input_xyz, include_input_dir=m.include_input_dir, use_viewdirs=m.use_viewdirs,
+            num_layers=cfg.models.coarse.num_layers, hidden_size=cfg.models.coarse.hidden_size, include_expression=True).to(device)
+    coarse = make(cfg.models.coarse)
+    fine = make(cfg.models.fine) if hasattr(cfg.models, "fine") else None
+    return coarse, fine
+
+
+def build_encoders(cfg):
+    c = cfg.models.coarse
+    enc_xyz = nerf.get_embedding_function(num_encoding_functions=c.num_encoding_fn_xyz, include_input=c.include_input_xyz,
+                                          log_sampling=c.log_sampling_xyz)
+    enc_dir = nerf.get_embedding_function(num_encoding_functions=c.num_encoding_fn_dir, include_input=c.include_input_dir,
+                                          log_sampling=c.log_sampling_dir) if c.use_viewdirs else None
+    return enc_xyz, enc_dir
+
+
+def load_background(basedir: str, H: int, W: int, device):
+    """The fixed background the trainer conditions on (TR:159-168): basedir/bg/00050.png scaled to the image size."""
+    from PIL import Image
+    p = os.path.join(basedir, "bg", "00050.png")
+    if not os.path.exists(p):
+        return None
+    im = Image.open(p)
+    im.thumbnail((H, W))
+    return torch.from_numpy(np.array(im).astype(np.float32) / 255.0)[..., :3].to(device)

@@ -1,0 +1,94 @@
+"""Frame-parallel NeRFace renderer: the per-frame loop of the reference's eval_transformed_rays.py (EV:392-498) with the
+test sequence sharded over GPUs (rank r renders frames r, r+W, ...; no collective on the data path).
+
+    torchrun --standalone --nproc-per-node 8 4d-facial-avatars_amd/launch/eval_sharded.py --config cfg.yml --checkpoint ckpt --savedir out
+
+Same CLI flags and checkpoint/dataset schema as the reference (`--config --checkpoint --savedir --save-disparity-image`).
+It renders the straight path (each test frame with its own pose and expression, latent code looked up through
+basedir/index_map.npy when present); the reference's hard-coded `ablate = 'view_dir'` experiment (EV:420-433, Quirk Q7)
+is not reproduced here -- run_one_iter_of_nerf still accepts `ray_directions_ablation` for callers that want it.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import common as CM
+from .common import D, nerf
+
+
+def to_uint8(img: torch.Tensor) -> np.ndarray:
+    return (img.clamp(0.0, 1.0) * 255.0).round().to(torch.uint8).cpu().numpy()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True)
+    ap.add_argument("--checkpoint", type=str, required=True)
+    ap.add_argument("--savedir", type=str, required=True)
+    ap.add_argument("--save-disparity-image", action="store_true")
+    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
+    args = ap.parse_args(argv)
+    rank, world, dev = CM.init_distributed()
+    nerf.set_mlp_precision(args.precision)
+    cfg = CM.load_config(args.config)
+    images, poses, render_poses, hwf, i_split, expressions, _, bboxs = nerf.load_flame_data(
+        cfg.dataset.basedir, half_res=cfg.dataset.half_res, testskip=cfg.dataset.testskip, test=True)
+    H, W, intrinsics = int(hwf[0]), int(hwf[1]), hwf[2]
+    enc_xyz, enc_dir = CM.build_encoders(cfg)
+    model_c, model_f = CM.build_models(cfg, dev)
+    ck = torch.load(args.checkpoint, map_location=dev)
+    model_c.load_state_dict(ck["model_coarse_state_dict"])
+    if ck.get("model_fine_state_dict") and model_f is not None:
+        model_f.load_state_dict(ck["model_fine_state_dict"])
+    H, W = int(ck.get("height", H)), int(ck.get("width", W))
+    background = ck.get("background")
+    if background is None:
+        background = CM.load_background(cfg.dataset.basedir, H, W, dev)
+    background = background.to(dev).float().reshape(-1, 3) if background is not None else None
+    latent_codes = ck.get("latent_codes")
+    latent_codes = latent_codes.to(dev) if latent_codes is not None else torch.zeros(1, 32, device=dev)
+    idx_map = None
+    p = os.path.join(cfg.dataset.basedir, "index_map.npy")
+    if os.path.exists(p):
+        idx_map = np.load(p).astype(int)
+    model_c.eval()
+    if model_f is not None:
+        model_f.eval()
+    os.makedirs(args.savedir, exist_ok=True)
+    if args.save_disparity_image:
+        os.makedirs(os.path.join(args.savedir, "disparity"), exist_ok=True)
+    from PIL import Image
+    n = poses.shape[0]
+    mine = D.shard_frames(n, rank, world)
+    times = []
+    for i in mine:
+        t0 = time.time()
+        row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
+        latent = latent_codes[min(max(row, 0), latent_codes.shape[0] - 1)]
+        with torch.no_grad():
+            ro, rd = nerf.get_ray_bundle(H, W, intrinsics, poses[i, :3, :4].to(dev))
+            out = nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
+                                            encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                            expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
+        rgb = out[3] if out[3] is not None else out[0]
+        Image.fromarray(to_uint8(rgb[..., :3])).save(os.path.join(args.savedir, f"{i:04d}.png"))
+        if args.save_disparity_image:
+            disp = out[4] if out[4] is not None else out[1]
+            d = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12)
+            Image.fromarray(to_uint8(d)).save(os.path.join(args.savedir, "disparity", f"{i:04d}.png"))
+        torch.cuda.synchronize()
+        times.append(time.time() - t0)
+    if times:
+        print(f"[rank {rank}] rendered {len(times)} of {n} frames, avg time per image: {sum(times) / len(times):.3f} s")
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    return mine
+
+
+if __name__ == "__main__":
+    main()

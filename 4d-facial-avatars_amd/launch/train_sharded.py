@@ -1,0 +1,126 @@
+"""Data-parallel NeRFace trainer: the loop of the reference's train_transformed_rays.py (TR:243-573) with one frame
+per rank per step and one flat RCCL gradient all-reduce.
+
+    torchrun --standalone --nproc-per-node 8 4d-facial-avatars_amd/launch/train_sharded.py --config cfg.yml [--load-checkpoint ckpt]
+
+Same CLI, YAML schema and checkpoint dictionary as the reference (`iter, model_coarse_state_dict, model_fine_state_dict,
+optimizer_state_dict, loss, psnr, background, latent_codes`; two optimizer param groups).  Differences, all outside the
+hot path: ray selection (importance map, p = 0.9 inside the bbox, TR:230-239) draws on the device with
+torch.multinomial instead of np.random.choice; no TensorBoard; rank 0 writes checkpoints; on resume the latent codes and
+background are restored *into* the tensors the optimizer already owns (the reference re-wraps them and the optimizer
+keeps stepping the stale ones).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import common as CM
+from .common import D, nerf
+
+
+def importance_maps(bboxs, H, W, p=0.9):
+    maps = []
+    for b in bboxs:
+        m = np.full((H, W), 1 - p, dtype=np.float64)
+        m[int(b[0]):int(b[1]), int(b[2]):int(b[3])] = p
+        maps.append((m / m.sum()).reshape(-1))
+    return maps
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=str, required=True, help="Path to (.yml) config file.")
+    ap.add_argument("--load-checkpoint", type=str, default="", help="Path to load saved checkpoint from.")
+    args = ap.parse_args(argv)
+    rank, world, dev = CM.init_distributed()
+    cfg = CM.load_config(args.config)
+    images, poses, render_poses, hwf, i_split, expressions, _, bboxs = nerf.load_flame_data(
+        cfg.dataset.basedir, half_res=cfg.dataset.half_res, testskip=cfg.dataset.testskip)
+    i_train, i_val, i_test = i_split
+    H, W, intrinsics = int(hwf[0]), int(hwf[1]), hwf[2]
+    seed = cfg.experiment.randomseed
+    np.random.seed(D.rank_seed(seed))
+    torch.manual_seed(seed)                                   # identical model init everywhere (also broadcast below)
+    enc_xyz, enc_dir = CM.build_encoders(cfg)
+    model_c, model_f = CM.build_models(cfg, dev)
+    background = CM.load_background(cfg.dataset.basedir, H, W, dev)
+    latent_codes = torch.zeros(len(i_train), 32, device=dev, requires_grad=True)
+    trainable = list(model_c.parameters()) + (list(model_f.parameters()) if model_f is not None else []) + [latent_codes]
+    groups = [{"params": trainable}]
+    if background is not None:
+        groups.append({"params": background, "lr": cfg.optimizer.lr})          # inert 2nd group, kept for checkpoint compatibility
+    optimizer = getattr(torch.optim, cfg.optimizer.type)(groups, lr=cfg.optimizer.lr)
+    start_iter = 0
+    if args.load_checkpoint and os.path.exists(args.load_checkpoint):
+        ck = torch.load(args.load_checkpoint, map_location=dev)
+        model_c.load_state_dict(ck["model_coarse_state_dict"])
+        if ck.get("model_fine_state_dict") and model_f is not None:
+            model_f.load_state_dict(ck["model_fine_state_dict"])
+        if ck.get("latent_codes") is not None:
+            with torch.no_grad():
+                latent_codes.copy_(ck["latent_codes"])
+        if ck.get("background") is not None and background is not None:
+            background.copy_(ck["background"])
+        optimizer.load_state_dict(ck["optimizer_state_dict"])
+        start_iter = int(ck["iter"])
+    D.broadcast_parameters(trainable)
+    reducer = D.GradientAllReducer(trainable)
+    maps = [torch.from_numpy(m).to(dev) for m in importance_maps(bboxs[i_train].numpy(), H, W)]
+    coords = torch.stack(nerf.meshgrid_xy(torch.arange(H, device=dev), torch.arange(W, device=dev)), dim=-1).reshape(-1, 2)
+    logdir = os.path.join(cfg.experiment.logdir, cfg.experiment.id)
+    if rank == 0:
+        os.makedirs(logdir, exist_ok=True)
+        with open(os.path.join(logdir, "config.yml"), "w") as f:
+            f.write(cfg.dump())
+    model_c.train()
+    if model_f is not None:
+        model_f.train()
+    n_rays = cfg.nerf.train.num_random_rays
+    t0 = time.time()
+    for i in range(start_iter, cfg.experiment.train_iters):
+        k = int(np.random.randint(len(i_train)))              # one frame per rank per step (TR:289)
+        img_idx = int(i_train[k])
+        target_img = images[img_idx].to(dev)
+        pose = poses[img_idx, :3, :4].to(dev)
+        expr = expressions[img_idx].to(dev)
+        latent = latent_codes[k]
+        ro, rd = nerf.get_ray_bundle(H, W, intrinsics, pose)
+        sel = coords[torch.multinomial(maps[k], n_rays, replacement=False)]
+        ro, rd = ro[sel[:, 0], sel[:, 1], :], rd[sel[:, 0], sel[:, 1], :]
+        target = target_img[sel[:, 0], sel[:, 1], :]
+        bg = background[sel[:, 0], sel[:, 1], :] if background is not None else None
+        rgb_c, _, _, rgb_f, _, _, _ = nerf.run_one_iter_of_nerf(
+            H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="train", encode_position_fn=enc_xyz,
+            encode_direction_fn=enc_dir, expressions=expr, background_prior=bg, latent_code=latent)
+        loss = torch.nn.functional.mse_loss(rgb_c[..., :3], target[..., :3])
+        if rgb_f is not None:
+            loss = loss + torch.nn.functional.mse_loss(rgb_f[..., :3], target[..., :3])
+        psnr = nerf.mse2psnr(loss.item())
+        loss = loss + 10 * (torch.norm(latent) * 0.0005)       # TR:375-387
+        loss.backward()
+        reducer.reduce()
+        optimizer.step()
+        optimizer.zero_grad()
+        lr_new = cfg.optimizer.lr * (cfg.scheduler.lr_decay_factor ** (i / (cfg.scheduler.lr_decay * 1000)))
+        for g in optimizer.param_groups:
+            g["lr"] = lr_new
+        if rank == 0 and (i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1):
+            print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {psnr:.4f} ({(time.time() - t0):.1f} s, {world} GPU)")
+        if rank == 0 and (i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1):
+            torch.save({"iter": i, "model_coarse_state_dict": model_c.state_dict(),
+                        "model_fine_state_dict": None if model_f is None else model_f.state_dict(),
+                        "optimizer_state_dict": optimizer.state_dict(), "loss": loss, "psnr": psnr,
+                        "background": None if background is None else background.data, "latent_codes": latent_codes.data},
+                       os.path.join(logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
+    if torch.distributed.is_initialized():
+        torch.distributed.barrier()
+    return logdir
+
+
+if __name__ == "__main__":
+    main()
