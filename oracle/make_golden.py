@@ -88,6 +88,31 @@ def main():
             blob[n] = a.numpy()
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
 
+    # ablation path (Quirk Q7, the call pattern of the shipped eval script): 48 rays in 3 chunks of 16, directions for the
+    # ENCODING taken from chunk 0 of another pose's rays for every chunk (T:81-82)
+    c = C.build_case("eval_det_64_128")
+    ro, rd, bg, tgt, idx = C.ray_subset(512, 512, 3, 48, seed=77)
+    ro2, rd2 = O.ray_bundle(512, 512, O.INTRINSICS, O.frame_pose(41))
+    rd_abl = rd2.reshape(-1, 3)[idx].contiguous()
+    c.update(n_rays=48, ro=ro, rd=rd, bg=bg, tgt=tgt, idx=idx)
+    mc, mf = ref_model(ref, c["p_coarse"]), ref_model(ref, c["p_fine"])
+    opt = ref_options(ref, 64, 128, False, 0.0)
+    opt.nerf.train.chunksize = 16
+    enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    with torch.no_grad():
+        out_ref = ref.run_one_iter_of_nerf(512, 512, None, mc, mf, ro.clone(), rd.clone(), opt, mode="train", encode_position_fn=enc_xyz,
+                                           encode_direction_fn=enc_dir, expressions=c["expr"], background_prior=bg,
+                                           latent_code=c["latent"], ray_directions_ablation=rd_abl.clone())
+    parts = [O.render_rays(c["p_coarse"], c["p_fine"], ro[k:k + 16], rd[k:k + 16], c["expr"], c["latent"], bg[k:k + 16], O.NEAR, O.FAR,
+                           64, 128, rd_view=rd_abl[:16]) for k in range(0, 48, 16)]          # per ray chunk, like the reference
+    out_or = [torch.cat(t, dim=0) for t in zip(*parts)]
+    # (the reference also feeds the MLP 16 POINTS at a time here -- chunksize is one number, T:20 -- so GEMM blocking differs
+    # from the oracle's and the comparison is to fp32 rounding, not bit-exact)
+    print("ablation max|d| coarse rgb:", float((out_ref[0] - out_or[0]).abs().max()), "fine rgb:", float((out_ref[3] - out_or[3]).abs().max()))
+    assert float((out_ref[0] - out_or[0]).abs().max()) < 1e-6
+    np.savez_compressed(os.path.join(OUT, "ablation_64_128.npz"), **{n: a.numpy() for n, a in zip(names7, out_ref)})
+
     # gradient fixture (reference autograd with the Q9 shim)
     c = C.build_case("train_rand_64_64")
     out_ref, g = run_reference(ref, c, grad=True)

@@ -147,12 +147,13 @@ def paper_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor,
     return torch.cat((rgb, sigma), dim=-1)
 
 
-def encode_points(ro, rd, z, near: float, far: float) -> torch.Tensor:
+def encode_points(ro, rd, z, near: float, far: float, rd_view=None) -> torch.Tensor:
     """run_network's input assembly (T:9-18): pts = ro + rd*z; 'view dirs' = ray_batch[..., -3:] which,
     because the viewdir concat is commented out (T:215-216), is (rd_z, near, far) (Quirk Q1).
     Returns (R*S, 87)."""
     pts = ro[:, None, :] + rd[:, None, :] * z[:, :, None]
-    fake_dirs = torch.stack((rd[:, 2], torch.full_like(rd[:, 2], near), torch.full_like(rd[:, 2], far)), dim=-1)
+    rv = rd if rd_view is None else rd_view            # ablation path (T:81-82, Quirk Q7): encoded direction from other rays
+    fake_dirs = torch.stack((rv[:, 2], torch.full_like(rv[:, 2], near), torch.full_like(rv[:, 2], far)), dim=-1)
     dirs = fake_dirs[:, None, :].expand(pts.shape)
     return torch.cat((posenc(pts.reshape(-1, 3), 10, True), posenc(dirs.reshape(-1, 3), 4, False)), dim=-1)
 
@@ -237,14 +238,14 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
 # --------------------------------------------------------------------------------------
 
 def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: float, n_coarse: int, n_fine: int,
-                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None):
+                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None):
     """Coarse pass -> hierarchical resample -> fine pass.  Returns the 7-tuple of T:162
     (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, weights_f[:, -1]).  Random tensors are injected
     (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates."""
     R = ro.shape[0]
     st = stages if stages is not None else {}
     z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype)
-    raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far), expr, latent).reshape(R, n_coarse, 4).clone()
+    raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far, rd_view), expr, latent).reshape(R, n_coarse, 4).clone()
     st["raw_c_mlp"] = raw.clone()
     if bg is not None:
         raw[:, -1, :3] = bg.to(raw.dtype)
@@ -255,7 +256,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
     z_mid = 0.5 * (z[:, 1:] + z[:, :-1])
     z_s = sample_pdf(z_mid, w_c[:, 1:-1], n_fine, u).detach()           # T:124: no gradient through the resampled depths
     z_f, _ = torch.sort(torch.cat((z, z_s), dim=-1), dim=-1)
-    raw_f = paper_mlp(p_fine, encode_points(ro, rd, z_f, near, far), expr, latent).reshape(R, n_coarse + n_fine, 4).clone()
+    raw_f = paper_mlp(p_fine, encode_points(ro, rd, z_f, near, far, rd_view), expr, latent).reshape(R, n_coarse + n_fine, 4).clone()
     st["raw_f_mlp"] = raw_f.clone()
     if bg is not None:
         raw_f[:, -1, :3] = bg.to(raw_f.dtype)
