@@ -46,9 +46,14 @@ struct NfSample {
 
 __device__ __forceinline__ float nf_sigmoid(float x) { return nf_div(1.0f, nf_add(1.0f, expf(-x))); }
 
+// mode bits: 1 = scale the sample spacing by |rd| (V:26), 2 = add 1e-6 to the last density (V:52-53), 4 = report the depth
+// map sum(w z) instead of the disparity.  NeRFace = 3; tiny_nerf's render_volume_density (tiny_nerf.py:68-107) = 4.
+#define NF_VR_NERFACE 3
+#define NF_VR_TINY 4
+
 __device__ __forceinline__ NfSample nf_load_sample(const float4* __restrict__ raw_row, const float* __restrict__ z_row,
                                                    const float* __restrict__ noise_row, const float* __restrict__ bg_ray,
-                                                   float rd_norm, int s, int S) {
+                                                   float rd_norm, int s, int S, int mode = NF_VR_NERFACE) {
     NfSample o;
     const float4 r = raw_row[s];
     const bool last = (s == S - 1);
@@ -56,10 +61,10 @@ __device__ __forceinline__ NfSample nf_load_sample(const float4* __restrict__ ra
     if (o.is_bg) { o.c[0] = bg_ray[0]; o.c[1] = bg_ray[1]; o.c[2] = bg_ray[2]; }
     else { o.c[0] = nf_sigmoid(r.x); o.c[1] = nf_sigmoid(r.y); o.c[2] = nf_sigmoid(r.z); }
     const float d = last ? 1e10f : nf_sub(z_row[s + 1], z_row[s]);
-    o.dist = nf_mul(d, rd_norm);
+    o.dist = (mode & 1) ? nf_mul(d, rd_norm) : d;
     o.pre = noise_row ? nf_add(r.w, noise_row[s]) : r.w;
     float sigma = fmaxf(o.pre, 0.0f);
-    if (last) sigma = nf_add(sigma, 1e-6f);                       // V:52-53
+    if (last && (mode & 2)) sigma = nf_add(sigma, 1e-6f);         // V:52-53
     o.alpha = nf_sub(1.0f, expf(-nf_mul(sigma, o.dist)));
     return o;
 }
@@ -76,7 +81,7 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
                                                            const float* __restrict__ rd, const float* __restrict__ noise,
                                                            const float* __restrict__ bg, int64_t n_rays, int S,
                                                            int white_bg, float* __restrict__ rgb, float* __restrict__ disp,
-                                                           float* __restrict__ acc, float* __restrict__ weights) {
+                                                           float* __restrict__ acc, float* __restrict__ weights, int mode) {
     const int lane = nf_lane();
     const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -84,7 +89,7 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
     const float* z_row = z + ray * S;
     const float* noise_row = noise ? noise + ray * S : nullptr;
     const float* bg_ray = bg ? bg + ray * 3 : nullptr;
-    const float norm = nf_rd_norm(rd + ray * 3);
+    const float norm = (mode & 1) ? nf_rd_norm(rd + ray * 3) : 1.0f;
     float carry = 1.0f;                        // running exclusive transmittance at the chunk start
     float a_r = 0.f, a_g = 0.f, a_b = 0.f, a_d = 0.f, a_w = 0.f;
     for (int base = 0; base < S; base += 64) {
@@ -92,7 +97,7 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
         const bool on = s < S;
         float alpha = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f, zz = 0.f;
         if (on) {
-            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S);
+            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S, mode);
             alpha = q.alpha; c0 = q.c[0]; c1 = q.c[1]; c2 = q.c[2]; zz = z_row[s];
         }
         const float b = on ? nf_add(nf_sub(1.0f, alpha), 1e-10f) : 1.0f;
@@ -101,7 +106,7 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
         if (lane == 0) excl = 1.0f;
         const float T = nf_mul(carry, excl);
         const float w = nf_mul(alpha, T);
-        if (on) weights[ray * S + s] = w;
+        if (on && weights) weights[ray * S + s] = w;
         a_r += w * c0; a_g += w * c1; a_b += w * c2; a_d += w * zz; a_w += w;
         carry = nf_mul(carry, __shfl(incl, 63, 64));
     }
@@ -110,7 +115,7 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
         if (white_bg) { const float k = nf_sub(1.0f, a_w); a_r += k; a_g += k; a_b += k; }
         rgb[ray * 3 + 0] = a_r; rgb[ray * 3 + 1] = a_g; rgb[ray * 3 + 2] = a_b;
         acc[ray] = a_w;
-        disp[ray] = nf_div(1.0f, fmaxf(1e-10f, nf_div(a_d, a_w)));
+        disp[ray] = (mode & 4) ? a_d : nf_div(1.0f, fmaxf(1e-10f, nf_div(a_d, a_w)));
     }
 }
 
@@ -122,7 +127,21 @@ extern "C" int nf_volume_render_fwd(const float* raw, const float* z, const floa
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_volume_render_fwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, z, rd, noise, bg, n_rays,
-                       n_samples, white_background, rgb, disp, acc, weights);
+                       n_samples, white_background, rgb, disp, acc, weights, NF_VR_NERFACE);
+    NF_RETURN_LAUNCH();
+}
+
+// tiny_nerf's render_volume_density (reference tiny_nerf.py:68-107): no background sample, no +1e-6, spacing not scaled by
+// |rd|; returns (rgb_map, depth_map, acc_map).  depth: (n_rays, n_samples).
+extern "C" int nf_render_volume_density(const float* raw, const float* depth, int64_t n_rays, int n_samples, float* rgb,
+                                        float* depth_map, float* acc, nf_stream_t stream) {
+    if (!raw || !depth || !rgb || !depth_map || !acc || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
+    if (n_rays == 0) return 0;
+    const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_volume_render_fwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, depth, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, n_rays, n_samples, 0, rgb, depth_map, acc, (float*)nullptr,
+                       NF_VR_TINY);
     NF_RETURN_LAUNCH();
 }
 

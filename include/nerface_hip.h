@@ -109,6 +109,18 @@ int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, cons
                          const float* bg, const float* d_rgb, int64_t n_rays, int n_samples,
                          int white_background, float* d_raw, nf_stream_t stream);
 
+/* ---- BASELINE config 1: tiny_nerf.py (reference tiny_nerf.py:12-181) ----------------------------------------------
+ * nf_tiny_mlp_fwd = compute_query_points_from_rays' pts = ro + rd*depth (tiny_nerf.py:59-63) + positional_encoding(., 10)
+ * + VeryTinyNerfModel.forward (63 -> 128 -> 128 -> 4).  params: HOST array of 6 device pointers
+ * (layer1.weight, layer1.bias, layer2.*, layer3.*).  depth: (n_rays, n_samples) if depth_per_ray else (n_samples).
+ * nf_render_volume_density = render_volume_density (tiny_nerf.py:68-107) -> rgb (R,3), depth_map (R), acc (R).     */
+size_t nf_tiny_packed_floats(void);
+int nf_tiny_pack(const float* const* params, float* packed, nf_stream_t stream);
+int nf_tiny_mlp_fwd(const float* packed, const float* ro, const float* rd, const float* depth, int depth_per_ray,
+                    int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+int nf_render_volume_density(const float* raw, const float* depth, int64_t n_rays, int n_samples, float* rgb,
+                             float* depth_map, float* acc, nf_stream_t stream);
+
 /* ---- K6: inverse-CDF sampler -- replaces sample_pdf_2 (H:344-387) --------------------------------- */
 /* bins (R,n_bins), weights (R,n_bins-1); u: row r at u + r*u_row_stride, n_out values
  * (u_row_stride = n_out for torch.rand draws, 0 to broadcast the det-mode linspace(0,1,n_out) table). */
