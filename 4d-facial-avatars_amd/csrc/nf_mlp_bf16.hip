@@ -150,7 +150,8 @@ extern "C" int nf_paper_pack_bf16(const float* const* params, void* stream_out, 
 // compiler-inserted vmcnt(0) would drain the pipeline) remains in the layer loop.  All LDS lives in ONE array.
 #define NFB_KPS 2                                   // k-steps per stage
 #define NFB_STAGE_BYTES (NFB_KPS * 8 * 2 * 1024)    // largest stage: 8 tiles x (hi, lo) x 1 KiB per k-step = 32 KiB
-#define NFB_NBUF 3
+#define NFB_NBUF 4                                  // ring depth; stage g + NFB_NBUF - 1 is prefetched while stage g is consumed
+#define NFB_LA (NFB_NBUF - 1)
 #define NFB_BIAS_BLOCKS 10                          // cond table (2332 f32) padded to 10 KiB
 #define NFB_LDS_BYTES (NFB_NBUF * NFB_STAGE_BYTES + NFB_BIAS_BLOCKS * 1024)
 
@@ -161,6 +162,8 @@ constexpr int stage0_of(int l) { int o = 0; for (int i = 0; i < l; ++i) o += sta
 constexpr int N_STAGES = stage0_of(NL);
 constexpr int layer_of_stage(int g) { int l = 0; while (l < NL && g >= stage0_of(l + 1)) ++l; return l; }
 constexpr int stage_nblk(int g) { return (g < 0 || g >= N_STAGES) ? 0 : 2 * NFB_KPS * NO[layer_of_stage(g)]; }
+// DMA pieces of this wave that may stay in flight when stage g ends: those of stages g+2 .. g+NFB_LA
+constexpr int inflight_after(int g) { int n = 0; for (int k = 2; k <= NFB_NBUF - 1; ++k) n += stage_nblk(g + k) / 4; return n; }
 constexpr int stage_blk0(int g) {
     if (g < 0 || g >= N_STAGES) return 0;
     const int l = layer_of_stage(g);
@@ -188,11 +191,19 @@ __device__ __forceinline__ void nfb_issue(const NfbCtx& cx, const char* gsrc, in
     }
 }
 
-// NFB_KPS k-steps of a layer with NO output tiles out of LDS buffer BUF; B operands bh/bl[s0 .. s0 + NFB_KPS).
-template <int NO, int BUF>
-__device__ __forceinline__ void nfb_compute_stage(const NfbCtx& cx, f32x16 (&acc)[8], const bf16x8 (&bh)[20], const bf16x8 (&bl)[20],
-                                                  int s0) {
-    const char* base = cx.lds + BUF * NFB_STAGE_BYTES + cx.lane * 16;
+// Stage G (compile time): consume stage G out of ring buffer G % 3 while prefetching stage G+2, then leave only that
+// newest DMA group in flight (counted vmcnt) and cross the workgroup barrier.
+// The four waves issue their DMA bursts at DIFFERENT points of the stage (wave w after a quarter w of its MFMAs): the
+// CU has one texture-address unit, and four simultaneous bursts right behind the barrier make every wave wait for all
+// 4 x NQ pieces to be accepted; staggered, a wave only waits for its own.
+template <int G, int NO>
+__device__ __forceinline__ void nfb_stage(const NfbCtx& cx, f32x16 (&acc)[8], const bf16x8 (&bh)[20], const bf16x8 (&bl)[20], int s0) {
+    constexpr int nb2 = nfb::stage_nblk(G + NFB_LA);
+    constexpr int blk2 = nfb::stage_blk0(G + NFB_LA);
+    constexpr int off2 = ((G + NFB_LA) % NFB_NBUF) * NFB_STAGE_BYTES;
+    constexpr int NM = NFB_KPS * 3 * NO;                      // MFMAs in this stage
+    const char* base = cx.lds + (G % NFB_NBUF) * NFB_STAGE_BYTES + cx.lane * 16;
+    int m = 0;                                                // MFMA counter (compile time after unrolling)
 #pragma unroll
     for (int u = 0; u < NFB_KPS; ++u) {
         bf16x8 ah[NO], al[NO];
@@ -202,21 +213,22 @@ __device__ __forceinline__ void nfb_compute_stage(const NfbCtx& cx, f32x16 (&acc
             al[nt] = *reinterpret_cast<const bf16x8*>(base + ((u * NO + nt) * 2 + 1) * 1024);
         }
 #pragma unroll
-        for (int nt = 0; nt < NO; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[nt], bh[s0 + u], acc[nt], 0, 0, 0);
+        for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int nt = 0; nt < NO; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nt], bl[s0 + u], acc[nt], 0, 0, 0);
+            for (int nt = 0; nt < NO; ++nt) {
+                if (nb2 > 0) {
 #pragma unroll
-        for (int nt = 0; nt < NO; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[nt], bh[s0 + u], acc[nt], 0, 0, 0);
+                    for (int w = 0; w < 4; ++w)
+                        if (m == (w * NM) / 4 && cx.wave == w)
+                            nfb_issue<(nb2 > 0 ? nb2 : 4)>(cx, cx.gsrc, blk2, off2);
+                }
+                const bf16x8& a = t == 0 ? al[nt] : ah[nt];
+                const bf16x8& b = t == 1 ? bl[s0 + u] : bh[s0 + u];
+                acc[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[nt], 0, 0, 0);
+                ++m;
+            }
     }
-}
-
-// Stage G (compile time): prefetch stage G+2, consume stage G, leave only the newest DMA group in flight, barrier.
-template <int G, int NO>
-__device__ __forceinline__ void nfb_stage(const NfbCtx& cx, f32x16 (&acc)[8], const bf16x8 (&bh)[20], const bf16x8 (&bl)[20], int s0) {
-    constexpr int nb2 = nfb::stage_nblk(G + 2);
-    if (nb2 > 0) nfb_issue<(nb2 > 0 ? nb2 : 4)>(cx, cx.gsrc, nfb::stage_blk0(G + 2), ((G + 2) % NFB_NBUF) * NFB_STAGE_BYTES);
-    nfb_compute_stage<NO, G % NFB_NBUF>(cx, acc, bh, bl, s0);
-    nfb_wait_vm<nb2 / 4>();                                   // stage G+1 (issued one stage ago) has landed for this wave
+    nfb_wait_vm<nfb::inflight_after(G)>();                    // stage G+1 has landed for this wave; later stages may still fly
     __builtin_amdgcn_s_barrier();                             // ... and for every wave; buffer G % 3 is free again
     asm volatile("" ::: "memory");
 }
@@ -293,6 +305,7 @@ k_paper_mlp_fwd_bf16(const char* __restrict__ wstream, const float* __restrict__
     nfb_issue<NFB_BIAS_BLOCKS>(cx, reinterpret_cast<const char*>(cond) + cx.lane * 16, 0, NFB_NBUF * NFB_STAGE_BYTES);
     nfb_issue<nfb::stage_nblk(0)>(cx, cx.gsrc, nfb::stage_blk0(0), 0);
     nfb_issue<nfb::stage_nblk(1)>(cx, cx.gsrc, nfb::stage_blk0(1), NFB_STAGE_BYTES);
+    if (NFB_LA > 2) nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
 
     // ---- inputs ---------------------------------------------------------------------------------------
     bf16x8 bh[20], bl[20];                                            // [0..4): PE k-steps (kept for the skip layer)
@@ -330,7 +343,7 @@ k_paper_mlp_fwd_bf16(const char* __restrict__ wstream, const float* __restrict__
         }
         nfb_split(x, dh, dl);
     }
-    nfb_wait_vm<nfb::stage_nblk(1) / 4>();                             // bias + stage 0 landed (stage 1 may be in flight)
+    nfb_wait_vm<nfb::inflight_after(-1)>();                            // bias + stage 0 landed (later stages may be in flight)
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
