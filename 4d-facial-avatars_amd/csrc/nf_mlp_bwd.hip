@@ -242,8 +242,8 @@ static void nf_build_dw_jobs(NfDwJob* j) {
     add(0, Z_D1, 128, 0, 128, S_D0, 128, 0, 128, G_D1, 128, CS_D0 + 128);
     add(0, Z_D2, 128, 0, 128, S_D1, 128, 0, 128, G_D2, 128, CS_D0 + 256);
     add(1, 0, 4, 0, 4, S_D2, 128, 0, 128, G_RGB, 128, CS_RGB);             // rows 0..2: fc_rgb.weight; cs[3] = d b_alpha
-    add(1, 0, 4, 3, 1, S_FEAT, 256, 0, 128, G_ALPHA, 256, -1);             // row 0: fc_alpha.weight
-    add(1, 0, 4, 3, 1, S_FEAT, 256, 128, 128, G_ALPHA + 128, 256, -1);
+    add(1, 0, 4, 0, 4, S_FEAT, 256, 0, 128, G_ALPHA, 256, -1);             // row 3 (d sigma): fc_alpha.weight
+    add(1, 0, 4, 0, 4, S_FEAT, 256, 128, 128, G_ALPHA + 128, 256, -1);
     // n == NF_DW_JOBS by construction
 }
 
@@ -265,76 +265,78 @@ k_paper_dw_gemm(const float* __restrict__ dz, const float* __restrict__ d_raw, c
     float* out = slabs + (int64_t)slice * SLAB_FLOATS + job.out_off;
     const int lda = job.lda, ldb = job.ldb;
 
-    // which of the 8 n-tiles / k-tiles hold valid columns for this lane
-    bool a_ok[8], b_ok[8];
+    // Row/column order inside the 128 x 128 tile is free, so it is chosen for 16-byte operand loads: lane (g, i) reads
+    // 4 consecutive features 64 sb + 4 i .. +3 of ONE point; component t of that float4 is the lane's operand for MFMA tile
+    // (sb, t), whose 16 rows are therefore the features 64 sb + 4 i' + t.  One load feeds four tiles.
+    bool a_ok[2], b_ok[2];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) { a_ok[q] = 16 * q + i < job.n_valid; b_ok[q] = 16 * q + i < job.k_valid; }
+    for (int q = 0; q < 2; ++q) { a_ok[q] = 64 * q + 4 * i < job.n_valid; b_ok[q] = 64 * q + 4 * i < job.k_valid; }
 
-    f32x4 acc[8][8];
+    f32x4 acc[8][8];                        // [4 sb + t][4 sk + t']
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
         for (int kt = 0; kt < 8; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float cs[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) cs[q] = 0.f;
+    f32x4 cs[2];
+    cs[0] = cs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    float a[8][4], b[8][4];
-    auto load_chunk = [&](int64_t p, float (&aa)[8][4], float (&bb)[8][4]) {
+    f32x4 a[4][2], b[4][2], an[4][2], bn[4][2];     // [step r][sub-block]
+    auto load_chunk = [&](int64_t p, f32x4 (&aa)[4][2], f32x4 (&bb)[4][2]) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t row = p + 4 * r + g;
             const bool rv = row < p_end;
-            const float* ar = A + row * lda + i;
-            const float* br = B + row * ldb + i;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                aa[q][r] = (rv && a_ok[q]) ? ar[16 * q] : 0.f;
-                bb[q][r] = (rv && b_ok[q]) ? br[16 * q] : 0.f;
+            for (int q = 0; q < 2; ++q) {
+                aa[r][q] = (rv && a_ok[q]) ? *reinterpret_cast<const f32x4*>(A + row * lda + 64 * q + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                bb[r][q] = (rv && b_ok[q]) ? *reinterpret_cast<const f32x4*>(B + row * ldb + 64 * q + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
         }
     };
-    float an[8][4], bn[8][4];
     if (p_begin < p_end) load_chunk(p_begin, a, b);
     for (int64_t p = p_begin; p < p_end; p += 16) {
         const bool more = p + 16 < p_end;
         if (more) load_chunk(p + 16, an, bn);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int r = 0; r < 4; ++r) {
+            cs[0] += a[r][0];
+            cs[1] += a[r][1];
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) {
-                cs[nt] += a[nt][r];
+            for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
                 for (int kt = 0; kt < 8; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[nt][r], b[kt][r], acc[nt][kt], 0, 0, 0);
-            }
+                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][nt >> 2][nt & 3], b[r][kt >> 2][kt & 3], acc[nt][kt], 0, 0, 0);
+        }
         if (more) {
 #pragma unroll
-            for (int q = 0; q < 8; ++q)
+            for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { a[q][r] = an[q][r]; b[q][r] = bn[q][r]; }
+                for (int q = 0; q < 2; ++q) { a[r][q] = an[r][q]; b[r][q] = bn[r][q]; }
         }
     }
-    // D layout: lane (g, c = i): rows n = 16 nt + 4 g + r, column k = 16 kt + i
+    // D of tile (nt = 4 sb + t, kt = 4 sk + t'): lane (g, c = i), reg r' -> row n = 64 sb + 4 (4 g + r') + t,
+    // column k = 64 sk + 4 c + t'.  For fixed (nt, r', sk) a lane holds 4 consecutive k: one 16-byte store.
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int nrow = 16 * nt + 4 * g + r;
+            const int nrow = 64 * (nt >> 2) + 4 * (4 * g + r) + (nt & 3);
             if (nrow < job.n_valid) {
 #pragma unroll
-                for (int kt = 0; kt < 8; ++kt)
-                    if (b_ok[kt]) out[(int64_t)nrow * job.ldo + 16 * kt + i] = acc[nt][kt][r];
+                for (int sk = 0; sk < 2; ++sk)
+                    if (b_ok[sk])
+                        *reinterpret_cast<f32x4*>(out + (int64_t)nrow * job.ldo + 64 * sk + 4 * i) =
+                            (f32x4){acc[nt][4 * sk + 0][r], acc[nt][4 * sk + 1][r], acc[nt][4 * sk + 2][r], acc[nt][4 * sk + 3][r]};
             }
         }
     if (job.cs_off >= 0) {
         float* cso = slabs + (int64_t)slice * SLAB_FLOATS + job.cs_off;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            float v = cs[q];
-            v += __shfl_xor(v, 16, 64);
-            v += __shfl_xor(v, 32, 64);
-            if (g == 0 && a_ok[q]) cso[16 * q + i] = v;
+        for (int q = 0; q < 2; ++q) {
+            f32x4 v = cs[q];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v[t] += __shfl_xor(v[t], 16, 64); v[t] += __shfl_xor(v[t], 32, 64); }
+            if (g == 0 && a_ok[q]) *reinterpret_cast<f32x4*>(cso + 64 * q + 4 * i) = v;
         }
     }
 }
@@ -404,7 +406,7 @@ __global__ void __launch_bounds__(256) k_paper_grad_unpack(const float* __restri
             case 11: v = sum[CS_L0 + 1280 + local]; break;
             case 12: v = sum[G_FEAT + local]; break;
             case 13: v = sum[CS_L0 + 1536 + local]; break;
-            case 14: v = sum[G_ALPHA + local]; break;          // fc_alpha.weight [1][256]
+            case 14: v = sum[G_ALPHA + 3 * 256 + local]; break;   // fc_alpha.weight [1][256] = row 3 (d sigma) of d_raw^T feat
             case 15: v = sum[CS_RGB + 3]; break;               // fc_alpha.bias
             case 16: {  // layers_dir.0.weight [128][280] = [feat 256 | PE4(rd_z, near, far) 24]
                 const int n = local / 280, col = local - 280 * n;

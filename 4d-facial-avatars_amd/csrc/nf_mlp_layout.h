@@ -121,7 +121,7 @@ constexpr int G_D0B = G_D0A + 128 * 256;         // [128][16]   (dir slot order)
 constexpr int G_D1 = G_D0B + 128 * 16;           // [128][128]
 constexpr int G_D2 = G_D1 + 128 * 128;
 constexpr int G_RGB = G_D2 + 128 * 128;          // [16][128]   rows 0..2 = fc_rgb.weight grad
-constexpr int G_ALPHA = G_RGB + 16 * 128;        // [16][256]   row 0 = fc_alpha.weight grad
+constexpr int G_ALPHA = G_RGB + 16 * 128;        // [16][256]   row 3 (the d sigma column of d_raw) = fc_alpha.weight grad
 constexpr int CS_L0 = G_ALPHA + 16 * 256;        // column sums of dZ = bias grads: 7 x 256
 constexpr int CS_D0 = CS_L0 + 7 * 256;           // 3 x 128
 constexpr int CS_RGB = CS_D0 + 3 * 128;          // 16: [d b_r, d b_g, d b_b, d b_alpha, 0...]
