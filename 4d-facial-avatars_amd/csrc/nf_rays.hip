@@ -112,3 +112,69 @@ extern "C" int nf_posenc(const float* x, int64_t n_rows, int dim, int n_freq, in
     hipLaunchKernelGGL(k_posenc, dim3(grid), dim3(256), 0, nf_s(stream), x, n_rows, dim, n_freq, include_input ? 1 : 0, out);
     NF_RETURN_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------
+// Eval post-processing on the device (reference eval_transformed_rays.py): cast_to_image (EV:184-190: clamp to [0,1],
+// x255, truncate to uint8 -- torchvision's ToPILImage does mul(255).byte()) and torch_normal_map (EV:84-119: back-project
+// the "depth" map the script passes (it is disp_fine), cross product of forward differences, normalise, *0.5+0.5, blend
+// towards white by the background weight, x255, truncate).  One thread per pixel; 16 B/pixel read, 6 B written.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void nf_backproject(const float* __restrict__ d, int r, int c, int width, float fx, float fy, float cx,
+                                               float cy, float (&p)[3]) {
+    const float dv = d[(int64_t)r * width + c];
+    p[0] = nf_div(nf_mul(nf_sub((float)c, cx), dv), fx);
+    p[1] = -nf_div(nf_mul(nf_sub((float)r, cy), dv), fy);
+    p[2] = dv;
+}
+
+__global__ void __launch_bounds__(256) k_eval_postprocess(const float* __restrict__ rgb, const float* __restrict__ depth,
+                                                          const float* __restrict__ weights, int height, int width, float fx, float fy,
+                                                          float cx, float cy, uint8_t* __restrict__ rgb_u8,
+                                                          uint8_t* __restrict__ normals_u8) {
+    const int64_t n = (int64_t)height * width;
+    for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(q / width), c = (int)(q - (int64_t)r * width);
+        if (rgb_u8) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float v = fminf(fmaxf(rgb[q * 3 + k], 0.0f), 1.0f);
+                rgb_u8[q * 3 + k] = (uint8_t)nf_mul(v, 255.0f);
+            }
+        }
+        if (normals_u8 && r < height - 1 && c < width - 1) {
+            float p0[3], pr[3], pc[3];
+            nf_backproject(depth, r, c, width, fx, fy, cx, cy, p0);
+            nf_backproject(depth, r + 1, c, width, fx, fy, cx, cy, pr);          // dx: next row
+            nf_backproject(depth, r, c + 1, width, fx, fy, cx, cy, pc);          // dy: next column
+            const float ax = nf_sub(pc[0], p0[0]), ay = nf_sub(pc[1], p0[1]), az = nf_sub(pc[2], p0[2]);   // dy
+            const float bx = nf_sub(pr[0], p0[0]), by = nf_sub(pr[1], p0[1]), bz = nf_sub(pr[2], p0[2]);   // dx
+            float nx = nf_sub(nf_mul(ay, bz), nf_mul(az, by));                   // cross(dy, dx)
+            float ny = nf_sub(nf_mul(az, bx), nf_mul(ax, bz));
+            float nz = nf_sub(nf_mul(ax, by), nf_mul(ay, bx));
+            const float len = sqrtf(nf_add(nf_add(nf_mul(nx, nx), nf_mul(ny, ny)), nf_mul(nz, nz)));
+            float v[3] = {nf_add(nf_mul(nf_div(nx, len), 0.5f), 0.5f), nf_add(nf_mul(nf_div(ny, len), 0.5f), 0.5f),
+                          nf_add(nf_mul(nf_div(nz, len), 0.5f), 0.5f)};
+            if (weights) {
+                const float m = weights[q];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if (m > 0.22f) v[k] = 1.0f;
+                    v[k] = nf_add(nf_mul(nf_sub(1.0f, m), v[k]), m);
+                }
+            }
+            uint8_t* o = normals_u8 + ((int64_t)r * (width - 1) + c) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) o[k] = (uint8_t)(int)nf_mul(v[k], 255.0f);
+        }
+    }
+}
+
+extern "C" int nf_eval_postprocess(const float* rgb, const float* depthmap, const float* weights, int height, int width, float fx,
+                                   float fy, float cx_w, float cy_h, uint8_t* rgb_u8, uint8_t* normals_u8, nf_stream_t stream) {
+    if (height <= 0 || width <= 0 || (rgb_u8 && !rgb) || (normals_u8 && !depthmap)) return NF_EINVAL;
+    const int64_t n = (int64_t)height * width;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_eval_postprocess, dim3(grid), dim3(256), 0, nf_s(stream), rgb, depthmap, weights, height, width, fx, fy,
+                       cx_w, cy_h, rgb_u8, normals_u8);
+    NF_RETURN_LAUNCH();
+}

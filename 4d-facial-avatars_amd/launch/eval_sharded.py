@@ -19,10 +19,11 @@ import torch
 
 from . import common as CM
 from .common import D, nerf
+from nerf import ops
 
 
 def to_uint8(img: torch.Tensor) -> np.ndarray:
-    return (img.clamp(0.0, 1.0) * 255.0).round().to(torch.uint8).cpu().numpy()
+    return (img.clamp(0.0, 1.0) * 255.0).to(torch.uint8).cpu().numpy()
 
 
 def main(argv=None):
@@ -31,6 +32,7 @@ def main(argv=None):
     ap.add_argument("--checkpoint", type=str, required=True)
     ap.add_argument("--savedir", type=str, required=True)
     ap.add_argument("--save-disparity-image", action="store_true")
+    ap.add_argument("--save-normals", action="store_true", help="also write the cleaned normal map of EV:469-471 (savedir/normals)")
     ap.add_argument("--precision", choices=["f32", "bf16x3"], default="bf16x3")
     args = ap.parse_args(argv)
     rank, world, dev = CM.init_distributed()
@@ -76,7 +78,13 @@ def main(argv=None):
                                             encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
                                             expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
         rgb = out[3] if out[3] is not None else out[0]
-        Image.fromarray(to_uint8(rgb[..., :3])).save(os.path.join(args.savedir, f"{i:04d}.png"))
+        # clamp / quantise (and the normal map) on the device: only uint8 crosses PCIe
+        rgb_u8, normals_u8 = ops.eval_postprocess(rgb[..., :3], out[4] if args.save_normals else None, out[6], intrinsics,
+                                                  want_normals=args.save_normals and out[4] is not None)
+        Image.fromarray(rgb_u8.cpu().numpy()).save(os.path.join(args.savedir, f"{i:04d}.png"))
+        if normals_u8 is not None:
+            os.makedirs(os.path.join(args.savedir, "normals"), exist_ok=True)
+            Image.fromarray(normals_u8.cpu().numpy()).save(os.path.join(args.savedir, "normals", f"{i:04d}.png"))
         if args.save_disparity_image:
             disp = out[4] if out[4] is not None else out[1]
             d = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12)

@@ -43,6 +43,9 @@ def main(argv=None):
         cfg.dataset.basedir, half_res=cfg.dataset.half_res, testskip=cfg.dataset.testskip)
     i_train, i_val, i_test = i_split
     H, W, intrinsics = int(hwf[0]), int(hwf[1]), hwf[2]
+    # frames stay on the host (the reference keeps the whole sequence in one CPU tensor, TR:61-72); pinned so that the one
+    # frame a step needs crosses PCIe asynchronously, overlapped with the previous step's kernels
+    images, poses, expressions = images.pin_memory(), poses.pin_memory(), expressions.pin_memory()
     seed = cfg.experiment.randomseed
     np.random.seed(D.rank_seed(seed))
     torch.manual_seed(seed)                                   # identical model init everywhere (also broadcast below)
@@ -85,9 +88,9 @@ def main(argv=None):
     for i in range(start_iter, cfg.experiment.train_iters):
         k = int(np.random.randint(len(i_train)))              # one frame per rank per step (TR:289)
         img_idx = int(i_train[k])
-        target_img = images[img_idx].to(dev)
-        pose = poses[img_idx, :3, :4].to(dev)
-        expr = expressions[img_idx].to(dev)
+        target_img = images[img_idx].to(dev, non_blocking=True)
+        pose = poses[img_idx, :3, :4].to(dev, non_blocking=True)
+        expr = expressions[img_idx].to(dev, non_blocking=True)
         latent = latent_codes[k]
         ro, rd = nerf.get_ray_bundle(H, W, intrinsics, pose)
         sel = coords[torch.multinomial(maps[k], n_rays, replacement=False)]

@@ -319,3 +319,28 @@ def sort_rows(x: torch.Tensor) -> torch.Tensor:
     with torch.cuda.device(dev):
         H.check(H.lib().nf_sort_rows(H.ptr(x), rows, n_cols, H.ptr(out), H.stream_ptr(dev)), "nf_sort_rows")
     return out
+
+
+# ---------------------------------------------------------------------------------------- eval post-processing
+def eval_postprocess(rgb, depthmap=None, weights=None, intrinsics=None, want_normals=True):
+    """(H,W,3) float image -> uint8 image (clamp, x255, truncate: EV:184-190) and, from the disparity/"depth" map the eval
+    script feeds torch_normal_map (EV:84-119), the cleaned uint8 normal map (H-1, W-1, 3).  Device tensors in and out."""
+    rgb = _c(rgb)
+    depthmap = _c(depthmap) if depthmap is not None else None
+    weights = _c(weights) if weights is not None else None
+    dev = H.require_device(rgb, depthmap, weights)
+    h, w = rgb.shape[0], rgb.shape[1]
+    rgb_u8 = torch.empty((h, w, 3), dtype=torch.uint8, device=dev)
+    normals = None
+    fx = fy = 1.0
+    cx = cy = 0.0
+    if want_normals and depthmap is not None:
+        import numpy as _np
+        a = _np.asarray(intrinsics, dtype=_np.float64).reshape(-1)
+        fx, fy = float(_np.float32(a[0])), float(_np.float32(a[1]))
+        cx, cy = float(_np.float32(a[2] * w)), float(_np.float32(a[3] * h))
+        normals = torch.empty((h - 1, w - 1, 3), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_eval_postprocess(H.ptr(rgb), H.ptr(depthmap), H.ptr(weights), h, w, fx, fy, cx, cy, H.ptr(rgb_u8),
+                                            H.ptr(normals), H.stream_ptr(dev)), "nf_eval_postprocess")
+    return rgb_u8, normals

@@ -121,6 +121,13 @@ int nf_tiny_mlp_fwd(const float* packed, const float* ro, const float* rd, const
 int nf_render_volume_density(const float* raw, const float* depth, int64_t n_rays, int n_samples, float* rgb,
                              float* depth_map, float* acc, nf_stream_t stream);
 
+/* ---- eval post-processing on the device -- replaces cast_to_image (eval_transformed_rays.py:184-190) and
+ *      torch_normal_map(depthmap, focal, weights, clean=True) (eval_transformed_rays.py:84-119) ------------------------
+ * rgb (H,W,3) -> rgb_u8 (H,W,3) = uint8(clamp(x,0,1)*255);  depthmap (H,W) [+ weights (H,W)] -> normals_u8 (H-1,W-1,3).
+ * Either output may be NULL.  cx_w = cx*W, cy_h = cy*H as in nf_ray_bundle.                                              */
+int nf_eval_postprocess(const float* rgb, const float* depthmap, const float* weights, int height, int width, float fx,
+                        float fy, float cx_w, float cy_h, uint8_t* rgb_u8, uint8_t* normals_u8, nf_stream_t stream);
+
 /* ---- K6: inverse-CDF sampler -- replaces sample_pdf_2 (H:344-387) --------------------------------- */
 /* bins (R,n_bins), weights (R,n_bins-1); u: row r at u + r*u_row_stride, n_out values
  * (u_row_stride = n_out for torch.rand draws, 0 to broadcast the det-mode linspace(0,1,n_out) table). */

@@ -349,3 +349,32 @@ def frame_conditioning(f: int, dtype=torch.float32):
 def synthetic_image(height: int, width: int, seed: int, dtype=torch.float32) -> torch.Tensor:
     g = torch.Generator().manual_seed(seed)
     return torch.rand((height, width, 3), generator=g, dtype=torch.float64).to(dtype)
+
+
+# --------------------------------------------------------------------------------------
+# eval post-processing (reference eval_transformed_rays.py:84-119, 184-190).  NOT pinned against the live reference:
+# the eval script cannot be imported without torchvision/imageio; restated from the source.
+# --------------------------------------------------------------------------------------
+
+def cast_to_u8(img: torch.Tensor) -> torch.Tensor:
+    """cast_to_image: clamp to [0,1]; torchvision's ToPILImage turns a float tensor into bytes with mul(255).byte()."""
+    return img.clamp(0.0, 1.0).mul(255).to(torch.uint8)
+
+
+def normal_map(depthmap: torch.Tensor, intrinsics, weights: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """torch_normal_map(depthmap, focal, weights, clean=True), square images (the script's W/H naming is swapped)."""
+    n_rows, n_cols = depthmap.shape
+    fx, fy, cx, cy = float(intrinsics[0]), float(intrinsics[1]), float(intrinsics[2]) * n_cols, float(intrinsics[3]) * n_rows
+    cc = torch.arange(n_cols, dtype=depthmap.dtype).view(1, -1).expand(n_rows, n_cols)
+    rr = torch.arange(n_rows, dtype=depthmap.dtype).view(-1, 1).expand(n_rows, n_cols)
+    pts = torch.stack((((cc - cx) * depthmap) / fx, -((rr - cy) * depthmap) / fy, depthmap), dim=-1)
+    dx = pts[1:, :, :] - pts[:-1, :, :]
+    dy = pts[:, 1:, :] - pts[:, :-1, :]
+    nrm = torch.cross(dy[:-1, :, :], dx[:, :-1, :], dim=2)
+    nrm = nrm / torch.sqrt(torch.sum(nrm * nrm, 2, keepdim=True))
+    nrm = nrm * 0.5 + 0.5
+    if weights is not None:
+        mask = weights[:-1, :-1].unsqueeze(-1).expand(-1, -1, 3)
+        nrm = torch.where(mask > 0.22, torch.ones_like(nrm), nrm)
+        nrm = (1 - mask) * nrm + mask * torch.ones_like(nrm)
+    return (nrm * 255).to(torch.uint8)

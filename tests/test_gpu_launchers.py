@@ -40,7 +40,8 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     # eval: 3 test frames -> PNGs, identical for both precisions to within quantisation
     out = os.path.join(base, "render")
     frames = eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out, "--save-disparity-image",
-                                "--precision", "f32"])
+                                "--save-normals", "--precision", "f32"])
+    assert np.asarray(__import__("PIL.Image").Image.open(os.path.join(out, "normals", "0000.png"))).shape == (31, 31, 3)
     assert frames == [0, 1, 2]
     from PIL import Image
     a = np.asarray(Image.open(os.path.join(out, "0001.png")))
@@ -50,3 +51,17 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     b = np.asarray(Image.open(os.path.join(out2, "0001.png")))
     assert a.shape == b.shape                      # (perturb=True in validation, as shipped: images differ by sampling noise)
     assert os.path.exists(os.path.join(out, "disparity", "0002.png"))
+
+
+def test_eval_postprocess_matches_oracle(hip_lib, gpu):
+    from nerf import ops
+    from oracle import nerface_oracle as O
+    g = torch.Generator().manual_seed(8)
+    rgb = torch.rand((48, 48, 3), generator=g) * 1.4 - 0.2
+    disp = torch.rand((48, 48), generator=g) * 0.5 + 1.0
+    w = torch.rand((48, 48), generator=g) * 0.5
+    u8, nrm = ops.eval_postprocess(rgb.to(gpu), disp.to(gpu), w.to(gpu), O.INTRINSICS)
+    assert torch.equal(u8.cpu(), O.cast_to_u8(rgb))
+    want = O.normal_map(disp, O.INTRINSICS, w)
+    d = (nrm.cpu().int() - want.int()).abs()
+    assert nrm.shape == (47, 47, 3) and int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.99     # truncation at an ulp boundary
