@@ -1,0 +1,231 @@
+// Second model family: ConditionalBlendshapeLearnableCodeNeRFModel (reference nerf/models.py:529-636) as every NeRFace
+// config instantiates it (num_layers 4, hidden 256, no skip, 10/4 encoding functions, include_input_dir False):
+//   x = layer1([PE(63) | expr/3 (76) | latent (32)])          (no activation)
+//   3 x relu(layers_xyz.i(x));  feat = relu(fc_feat(x));  sigma = fc_alpha(x)   (reads x, not feat)
+//   relu(layers_dir.0([feat | PE4(dir) (24)])) -> rgb = fc_rgb
+// Inference forward, exact-f32 MFMA, same building blocks / folding rules as the paper model (nf_mlp.hip).
+#include <vector>
+#include <mutex>
+#include "nf_mlp_dev.h"
+
+namespace nlc {
+constexpr int FRAG = 256;
+constexpr int OFF_L1 = 0;                              // 4 PE chunks x 16 tiles
+constexpr int OFF_X0 = OFF_L1 + 4 * 16 * FRAG;         // 16 x 16 each
+constexpr int OFF_X1 = OFF_X0 + 16 * 16 * FRAG;
+constexpr int OFF_X2 = OFF_X1 + 16 * 16 * FRAG;
+constexpr int OFF_ALPHA = OFF_X2 + 16 * 16 * FRAG;     // 16 chunks x 1 tile (row 0)
+constexpr int OFF_FEAT = OFF_ALPHA + 16 * 1 * FRAG;
+constexpr int OFF_DIR = OFF_FEAT + 16 * 16 * FRAG;     // 16 feat chunks + 1 dir chunk, 8 tiles
+constexpr int OFF_RGB = OFF_DIR + 17 * 8 * FRAG;       // 8 chunks x 1 tile (rows 0..2)
+constexpr int OFF_WC1 = OFF_RGB + 8 * 1 * FRAG;        // [256][108] layer1.weight[:, 63:171]
+constexpr int OFF_WCD = OFF_WC1 + 256 * 108;           // [128][16]  layers_dir.0.weight[:, 256+6f+3sc+{1,2}]
+constexpr int OFF_BIAS = OFF_WCD + 128 * 16;
+constexpr int B_L1 = 0, B_X0 = 256, B_X1 = 512, B_X2 = 768, B_FEAT = 1024, B_ALPHA = 1280, B_DIR = 1296, B_RGB = 1424;
+constexpr int BIAS_FLOATS = 1440;
+constexpr int B_CVEC = BIAS_FLOATS, B_DVEC = B_CVEC + 108, COND_FLOATS = B_DVEC + 16;
+constexpr int PACKED = OFF_BIAS + BIAS_FLOATS;
+constexpr int NPARAMS = 16;   // layer1, layers_xyz.0..2, layers_dir.0, fc_alpha, fc_rgb, fc_feat (weight, bias each)
+}  // namespace nlc
+
+struct NfLcodePtrs { const float* p[nlc::NPARAMS]; };
+
+static void nf_lcode_table(std::vector<uint32_t>& t) {
+    using namespace nlc;
+    const uint32_t Z = 0xFF000000u;
+    t.assign(PACKED, Z);
+    auto code = [](int tensor, int row, int col, int ncols) { return ((uint32_t)tensor << 24) | (uint32_t)(row * ncols + col); };
+    auto fill = [&](int off, int nk, int no_tiles, int tensor, int n_out, int n_cols, auto col_of) {
+        for (int ni = 0; ni < nk; ++ni)
+            for (int no = 0; no < no_tiles; ++no)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int g = lane >> 4, i = lane & 15, n = 16 * no + i, col = col_of(16 * ni + 4 * g + r);
+                        if (n < n_out && col >= 0) t[(size_t)off + ((size_t)(ni * no_tiles + no) * 64 + lane) * 4 + r] = code(tensor, n, col, n_cols);
+                    }
+    };
+    auto ident = [](int s) { return s; };
+    fill(OFF_L1, 4, 16, 0, 256, 171, [](int s) { return nfl::pe_slot_to_col(s); });
+    fill(OFF_X0, 16, 16, 2, 256, 256, ident);
+    fill(OFF_X1, 16, 16, 4, 256, 256, ident);
+    fill(OFF_X2, 16, 16, 6, 256, 256, ident);
+    fill(OFF_ALPHA, 16, 1, 10, 1, 256, ident);
+    fill(OFF_FEAT, 16, 16, 14, 256, 256, ident);
+    fill(OFF_DIR, 17, 8, 8, 128, 280, [](int s) {
+        if (s < 256) return s;
+        const int g = ((s - 256) >> 2) & 3, r = (s - 256) & 3;
+        return r < 2 ? 256 + 6 * g + 3 * r : -1;
+    });
+    fill(OFF_RGB, 8, 1, 12, 3, 128, ident);
+    for (int n = 0; n < 256; ++n)
+        for (int k = 0; k < 108; ++k) t[OFF_WC1 + n * 108 + k] = code(0, n, 63 + k, 171);
+    for (int n = 0; n < 128; ++n)
+        for (int f = 0; f < 4; ++f)
+            for (int sc = 0; sc < 2; ++sc)
+                for (int comp = 1; comp < 3; ++comp) t[OFF_WCD + n * 16 + 4 * f + 2 * sc + (comp - 1)] = code(8, n, 256 + 6 * f + 3 * sc + comp, 280);
+    const int b256[5] = {1, 3, 5, 7, 15};          // layer1, layers_xyz.0..2, fc_feat biases
+    for (int l = 0; l < 5; ++l)
+        for (int n = 0; n < 256; ++n) t[OFF_BIAS + 256 * l + n] = code(b256[l], 0, n, 256);
+    t[OFF_BIAS + B_ALPHA] = code(11, 0, 0, 1);
+    for (int n = 0; n < 128; ++n) t[OFF_BIAS + B_DIR + n] = code(9, 0, n, 128);
+    for (int n = 0; n < 3; ++n) t[OFF_BIAS + B_RGB + n] = code(13, 0, n, 3);
+}
+
+__global__ void __launch_bounds__(256) k_lcode_pack(NfLcodePtrs ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t code = table[i], id = code >> 24;
+        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+    }
+}
+
+static std::mutex g_lcode_mutex;
+static uint32_t* g_lcode_table[64] = {nullptr};
+
+extern "C" size_t nf_lcode_packed_floats(void) { return (size_t)nlc::PACKED; }
+extern "C" size_t nf_lcode_cond_floats(void) { return (size_t)nlc::COND_FLOATS; }
+
+extern "C" int nf_lcode_pack(const float* const* params, float* packed, nf_stream_t stream) {
+    if (!params || !packed) return NF_EINVAL;
+    NfLcodePtrs ptrs;
+    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lock(g_lcode_mutex);
+        if (!g_lcode_table[dev]) {
+            std::vector<uint32_t> host;
+            nf_lcode_table(host);
+            uint32_t* d = nullptr;
+            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
+            g_lcode_table[dev] = d;
+        }
+    }
+    hipLaunchKernelGGL(k_lcode_pack, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_table[dev], packed, (int)nlc::PACKED);
+    NF_RETURN_LAUNCH();
+}
+
+__global__ void __launch_bounds__(256) k_lcode_condition(const float* __restrict__ packed, const float* __restrict__ expr,
+                                                         const float* __restrict__ latent, float near_z, float far_z,
+                                                         float* __restrict__ cond) {
+    using namespace nlc;
+    __shared__ float cvec[108];
+    __shared__ float dvec[16];
+    const int tid = threadIdx.x;
+    if (tid < 76) cvec[tid] = nf_div(nf_mul(expr[tid], 1.0f), 3.0f);
+    else if (tid < 108) cvec[tid] = latent[tid - 76];
+    if (tid >= 128 && tid < 144) {
+        const int k = tid - 128, f = k >> 2, sc = (k >> 1) & 1, comp = k & 1;
+        const float a = nf_mul(comp ? far_z : near_z, exp2f((float)f));
+        dvec[k] = sc ? cosf(a) : sinf(a);
+    }
+    __syncthreads();
+    const float* bias = packed + OFF_BIAS;
+    for (int i = blockIdx.x * blockDim.x + tid; i < COND_FLOATS; i += gridDim.x * blockDim.x) {
+        if (i >= B_CVEC) { cond[i] = i < B_DVEC ? cvec[i - B_CVEC] : dvec[i - B_DVEC]; continue; }
+        float v = bias[i];
+        if (i < B_X0) {
+            const float* w = packed + OFF_WC1 + i * 108;
+            float s = 0.0f;
+            for (int k = 0; k < 108; ++k) s = fmaf(w[k], cvec[k], s);
+            v += s;
+        } else if (i >= B_DIR && i < B_DIR + 128) {
+            const float* w = packed + OFF_WCD + (i - B_DIR) * 16;
+            float s = 0.0f;
+            for (int k = 0; k < 16; ++k) s = fmaf(w[k], dvec[k], s);
+            v += s;
+        }
+        cond[i] = v;
+    }
+}
+
+extern "C" int nf_lcode_condition(const float* packed, const float* expr76, const float* latent32, float near_z, float far_z,
+                                  float* cond, nf_stream_t stream) {
+    if (!packed || !expr76 || !latent32 || !cond) return NF_EINVAL;
+    hipLaunchKernelGGL(k_lcode_condition, dim3((nlc::COND_FLOATS + 255) / 256), dim3(256), 0, nf_s(stream), packed, expr76, latent32,
+                       near_z, far_z, cond);
+    NF_RETURN_LAUNCH();
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
+                const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z, int64_t n_points, int S,
+                float* __restrict__ raw) {
+    using namespace nlc;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
+    f32x4 pe[NT][4];
+    f32x4 dirf[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const int64_t ray = p / S;
+        const float zz = z[p];
+        const float px = nf_add(ro[ray * 3 + 0], nf_mul(rd[ray * 3 + 0], zz));
+        const float py = nf_add(ro[ray * 3 + 1], nf_mul(rd[ray * 3 + 1], zz));
+        const float pz = nf_add(ro[ray * 3 + 2], nf_mul(rd[ray * 3 + 2], zz));
+        nf_encode_point(px, py, pz, g, pe[t]);
+        float s, cs;
+        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
+        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+    }
+    f32x4 acc[NT][16];
+    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
+    nf_store_act<NT, 16, false>(acc, act4, lane);
+    nf_init_acc<NT, 16>(acc, cond + B_X0, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_X0 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 16>(acc, cond + B_X1, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_X1 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 16>(acc, cond + B_X2, lane);
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_X2 / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 1>(acc, cond + B_ALPHA, lane);                       // fc_alpha(x)
+    nf_mma_from_lds<NT, 1>(acc, W + OFF_ALPHA / 4, 16, act4, lane);
+    float sigma_raw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
+    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);                       // feat = relu(fc_feat(x))
+    nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
+    nf_store_act<NT, 16, true>(acc, act4, lane);
+    nf_init_acc<NT, 8>(acc, cond + B_DIR, lane);                         // relu(layers_dir.0([feat | dir]))
+    nf_mma_from_lds<NT, 8>(acc, W + OFF_DIR / 4, 16, act4, lane);
+    nf_mma_from_regs<NT, 8, 1>(acc, W + OFF_DIR / 4 + 16 * 8 * 64, dirf, lane);
+    nf_store_act<NT, 8, true>(acc, act4, lane);
+    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
+    nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t p = p0 + 16 * t + c;
+            if (p < n_points) reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+        }
+    }
+}
+
+extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    if (!packed || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
+    const int64_t n_points = n_rays * n_samples;
+    if (n_points == 0) return 0;
+    constexpr int NT = NF_MLP_NT;
+    const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
+    const int64_t grid = (n_points + per_block - 1) / per_block;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL((k_lcode_mlp_fwd<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro, rd,
+                       rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+    NF_RETURN_LAUNCH();
+}

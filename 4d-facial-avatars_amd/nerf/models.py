@@ -68,8 +68,121 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
             self._hip_weights = hw
         return hw
 
+    # ---- what run_one_iter_of_nerf calls (one interface for every fused model family) -------------------------
+    def hip_forward(self, ro, rd, z, rd_view, expr, latent, near, far, need_grad):
+        """raw (R, S, 4) for the points ro + rd*z; `state` is what hip_backward needs (None when no gradient is wanted)."""
+        hw = self.hip_weights()
+        packed = hw.get()
+        cond = ops.paper_condition(packed, expr, latent, near, far)
+        if need_grad:
+            raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view)
+            return raw, (packed, cond, saved)
+        if ops.get_mlp_precision() == "bf16x3":
+            return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
+        return ops.paper_mlp_fwd(packed, cond, ro, rd, z, rd_view), None
+
+    def hip_backward(self, state, z, d_raw):
+        """d_raw -> ([gradients in hip_param_list() order, None for layers_dir.3], d_latent (32))."""
+        packed, cond, saved = state
+        return ops.paper_mlp_bwd(self, packed, cond, None, None, z, None, None, None, d_raw, saved)
+
     def forward(self, x, expr=None, latent_code=None, **kwargs):
         raise NotImplementedError(
             "ConditionalBlendshapePaperNeRFModel.forward on pre-encoded (N, 87) inputs is not part of the MI355X hot "
             "path: call nerf.run_one_iter_of_nerf(...), which evaluates the network inside the fused HIP kernel "
             "(positional encoding included) exactly as train_transformed_rays.py / eval_transformed_rays.py do.")
+
+
+LCODE_KEYS = [f"{n}.{p}" for n in ("layer1", "layers_xyz.0", "layers_xyz.1", "layers_xyz.2", "layers_dir.0", "fc_alpha", "fc_rgb", "fc_feat")
+              for p in ("weight", "bias")]
+
+
+class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
+    r"""Second NeRFace model family (reference nerf/models.py:529-636; 6 config entries): layer1 without activation, three
+    256-wide ReLU layers, feat = relu(fc_feat(x)), sigma = fc_alpha(x), one 280 -> 128 direction layer, fc_rgb.
+    Same constructor signature, parameter names and shapes as the reference, so its checkpoints load.  The MI355X build
+    provides the inference forward (exact-f32 fused kernel) for the geometry the configs use: num_layers=4,
+    hidden_size=256 (the trainer never passes skip_connect_every, TR:100-109), 10/4 encoding functions; training this
+    family is not provided."""
+
+    def __init__(self, num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4,
+                 include_input_xyz=True, include_input_dir=True, use_viewdirs=True, include_expression=True, latent_code_dim=32):
+        super().__init__()
+        include_input_xyz = 3 if include_input_xyz else 0
+        include_input_dir = 3 if include_input_dir else 0
+        include_expression = 76 if include_expression else 0
+        self.dim_xyz = include_input_xyz + 2 * 3 * num_encoding_fn_xyz
+        self.dim_dir = include_input_dir + 2 * 3 * num_encoding_fn_dir if use_viewdirs else 0
+        self.dim_expression = include_expression
+        self.skip_connect_every = skip_connect_every
+        self.dim_latent_code = latent_code_dim
+        self.layers_expr = None
+        d_in = self.dim_xyz + self.dim_expression + self.dim_latent_code
+        self.layer1 = torch.nn.Linear(d_in, hidden_size)
+        self.layers_xyz = torch.nn.ModuleList()
+        for i in range(num_layers - 1):
+            skip = i % self.skip_connect_every == 0 and i > 0 and i != num_layers - 1
+            self.layers_xyz.append(torch.nn.Linear(self.dim_xyz + hidden_size + self.dim_expression + self.dim_latent_code if skip
+                                                   else hidden_size, hidden_size))
+        self.use_viewdirs = use_viewdirs
+        if self.use_viewdirs:
+            self.layers_dir = torch.nn.ModuleList()
+            self.layers_dir.append(torch.nn.Linear(self.dim_dir + hidden_size, hidden_size // 2))
+            self.fc_alpha = torch.nn.Linear(hidden_size, 1)
+            self.fc_rgb = torch.nn.Linear(hidden_size // 2, 3)
+            self.fc_feat = torch.nn.Linear(hidden_size, hidden_size)
+        else:
+            self.fc_out = torch.nn.Linear(hidden_size, 4)
+        self.relu = torch.nn.functional.relu
+        self.sigmoid = torch.sigmoid
+        self._packed = None
+        self._sig = None
+
+    def fused_supported(self) -> bool:
+        return (self.use_viewdirs and self.dim_xyz == 63 and self.dim_dir == 24 and self.dim_expression == 76
+                and self.dim_latent_code == 32 and self.layer1.out_features == 256 and len(self.layers_xyz) == 3
+                and all(l.in_features == 256 for l in self.layers_xyz))
+
+    def hip_param_list(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in LCODE_KEYS]
+
+    def _hip_packed(self):
+        import ctypes as C
+        from . import _hip as H
+        ps = self.hip_param_list()
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        if self._packed is None or sig != self._sig:
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            self._packed = torch.empty(lib.nf_lcode_packed_floats(), dtype=torch.float32, device=dev)
+            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_lcode_pack(arr, H.ptr(self._packed), H.stream_ptr(dev)), "nf_lcode_pack")
+            self._sig = sig
+        return self._packed
+
+    def hip_forward(self, ro, rd, z, rd_view, expr, latent, near, far, need_grad):
+        import numpy as np
+        from . import _hip as H
+        if need_grad:
+            raise NotImplementedError("training ConditionalBlendshapeLearnableCodeNeRFModel is not provided by the MI355X build "
+                                      "(inference only); wrap the call in torch.no_grad()")
+        packed = self._hip_packed()
+        lib = H.lib()
+        dev = H.require_device(packed, ro, rd, z, rd_view, expr, latent)
+        cond = torch.empty(lib.nf_lcode_cond_floats(), dtype=torch.float32, device=dev)
+        n_rays, n_samples = z.shape
+        raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_lcode_condition(H.ptr(packed), H.ptr(expr), H.ptr(latent), float(np.float32(near)), float(np.float32(far)),
+                                           H.ptr(cond), H.stream_ptr(dev)), "nf_lcode_condition")
+            H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                         n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
+        return raw, None
+
+    def hip_backward(self, state, z, d_raw):
+        raise NotImplementedError("training ConditionalBlendshapeLearnableCodeNeRFModel is not provided by the MI355X build")
+
+    def forward(self, x, expr=None, latent_code=None, **kwargs):
+        raise NotImplementedError("evaluate this model through nerf.run_one_iter_of_nerf(...) (fused HIP kernel)")

@@ -50,29 +50,15 @@ class _RenderChunk(torch.autograd.Function):
         dev = ro.device
         n_rays = ro.shape[0]
 
-        split = (not need_grad) and ops.get_mlp_precision() == "bf16x3"
-        pk_c = model_c.hip_weights().get()
-        cond_c = ops.paper_condition(pk_c, expr, latent, near, far)
+        lat_d = latent.detach().reshape(-1).contiguous()
         z_c = ops.sample_coarse(n_rays, nc, near, far, dev, t_rand)
-        if need_grad:
-            raw_c, saved_c = ops.paper_mlp_fwd_train(pk_c, cond_c, ro, rd, z_c, rd_view)
-        elif split:
-            raw_c, saved_c = ops.paper_mlp_fwd_bf16(model_c.hip_weights().get_bf16(), cond_c, ro, rd, z_c, rd_view), None
-        else:
-            raw_c, saved_c = ops.paper_mlp_fwd(pk_c, cond_c, ro, rd, z_c, rd_view), None
+        raw_c, state_c = model_c.hip_forward(ro, rd, z_c, rd_view, expr, lat_d, near, far, need_grad)
         rgb_c, disp_c, acc_c, w_c = ops.volume_render_fwd(raw_c, z_c, rd, noise_c, bg, white)
         outs = [rgb_c, disp_c, acc_c]
         ctx.has_fine = nf > 0 and model_f is not None
         if ctx.has_fine:
             z_f = ops.resample_merge(z_c, w_c, nf, u)
-            pk_f = model_f.hip_weights().get()
-            cond_f = ops.paper_condition(pk_f, expr, latent, near, far)
-            if need_grad:
-                raw_f, saved_f = ops.paper_mlp_fwd_train(pk_f, cond_f, ro, rd, z_f, rd_view)
-            elif split:
-                raw_f, saved_f = ops.paper_mlp_fwd_bf16(model_f.hip_weights().get_bf16(), cond_f, ro, rd, z_f, rd_view), None
-            else:
-                raw_f, saved_f = ops.paper_mlp_fwd(pk_f, cond_f, ro, rd, z_f, rd_view), None
+            raw_f, state_f = model_f.hip_forward(ro, rd, z_f, rd_view, expr, lat_d, near, far, need_grad)
             rgb_f, disp_f, acc_f, w_f = ops.volume_render_fwd(raw_f, z_f, rd, noise_f, bg, white)
             w_last = w_f[:, -1].contiguous()
             outs += [rgb_f, disp_f, acc_f, w_last]
@@ -82,11 +68,10 @@ class _RenderChunk(torch.autograd.Function):
         if need_grad:
             ctx.cfg = cfg
             ctx.n_params_c = n_params_c
-            ctx.save_for_backward(ro, rd, rd_view, bg, expr, latent, noise_c, noise_f, z_c, raw_c, pk_c, cond_c,
-                                  *(saved_c or ()))
-            ctx.n_saved_c = len(saved_c or ())
+            ctx.save_for_backward(rd, bg, noise_c, noise_f, z_c, raw_c, latent)
+            ctx.state_c = state_c
             if ctx.has_fine:
-                ctx.fine = (z_f, raw_f, pk_f, cond_f, saved_f)
+                ctx.fine = (z_f, raw_f, state_f)
         nondiff = [o for i, o in enumerate(outs) if not (i == 0 or (ctx.has_fine and i == 3))]
         ctx.mark_non_differentiable(*nondiff)
         return tuple(outs)
@@ -94,25 +79,25 @@ class _RenderChunk(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *grads):
         cfg = ctx.cfg
-        (ro, rd, rd_view, bg, expr, latent, noise_c, noise_f, z_c, raw_c, pk_c, cond_c, *saved_c) = ctx.saved_tensors
+        rd, bg, noise_c, noise_f, z_c, raw_c, latent = ctx.saved_tensors
         model_c, model_f = cfg["model_coarse"], cfg["model_fine"]
         white = cfg["white_background"]
         d_rgb_c = grads[0]
-        g_latent = torch.zeros(32, dtype=torch.float32, device=ro.device)
+        g_latent = torch.zeros(32, dtype=torch.float32, device=rd.device)
         grads_c = [None] * ctx.n_params_c
         grads_f = []
         if d_rgb_c is not None:
             d_raw_c = ops.volume_render_bwd(raw_c, z_c, rd, noise_c, bg, d_rgb_c, white)
-            grads_c, gl = ops.paper_mlp_bwd(model_c, pk_c, cond_c, ro, rd, z_c, rd_view, expr, latent, d_raw_c, saved_c)
+            grads_c, gl = model_c.hip_backward(ctx.state_c, z_c, d_raw_c)
             g_latent = g_latent + gl
+        ctx.state_c = None
         if ctx.has_fine:
-            z_f, raw_f, pk_f, cond_f, saved_f = ctx.fine
+            z_f, raw_f, state_f = ctx.fine
             d_rgb_f = grads[3]
-            n_f = len(model_f.hip_param_list())
-            grads_f = [None] * n_f
+            grads_f = [None] * len(model_f.hip_param_list())
             if d_rgb_f is not None:
                 d_raw_f = ops.volume_render_bwd(raw_f, z_f, rd, noise_f, bg, d_rgb_f, white)
-                grads_f, gl = ops.paper_mlp_bwd(model_f, pk_f, cond_f, ro, rd, z_f, rd_view, expr, latent, d_raw_f, saved_f)
+                grads_f, gl = model_f.hip_backward(state_f, z_f, d_raw_f)
                 g_latent = g_latent + gl
             ctx.fine = None
         g_latent = g_latent.reshape(latent.shape) if ctx.needs_input_grad[6] else None

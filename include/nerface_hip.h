@@ -109,6 +109,17 @@ int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, cons
                          const float* bg, const float* d_rgb, int64_t n_rays, int n_samples,
                          int white_background, float* d_raw, nf_stream_t stream);
 
+/* ---- second model family: ConditionalBlendshapeLearnableCodeNeRFModel.forward (M:590-636) + run_network (T:9-33), inference.
+ * params: HOST array of 16 device pointers in state_dict order (layer1, layers_xyz.0..2, layers_dir.0, fc_alpha, fc_rgb,
+ * fc_feat; weight then bias).  Same pack / condition / forward protocol and argument meaning as the paper model.      */
+size_t nf_lcode_packed_floats(void);
+size_t nf_lcode_cond_floats(void);
+int nf_lcode_pack(const float* const* params, float* packed, nf_stream_t stream);
+int nf_lcode_condition(const float* packed, const float* expr76, const float* latent32, float near_z, float far_z,
+                       float* cond, nf_stream_t stream);
+int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                     const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+
 /* ---- BASELINE config 1: tiny_nerf.py (reference tiny_nerf.py:12-181) ----------------------------------------------
  * nf_tiny_mlp_fwd = compute_query_points_from_rays' pts = ro + rd*depth (tiny_nerf.py:59-63) + positional_encoding(., 10)
  * + VeryTinyNerfModel.forward (63 -> 128 -> 128 -> 4).  params: HOST array of 6 device pointers

@@ -113,6 +113,25 @@ def main():
     assert float((out_ref[0] - out_or[0]).abs().max()) < 1e-6
     np.savez_compressed(os.path.join(OUT, "ablation_64_128.npz"), **{n: a.numpy() for n, a in zip(names7, out_ref)})
 
+    # second model family (ConditionalBlendshapeLearnableCodeNeRFModel), eval forward, built as the trainer builds it
+    c = C.build_case("eval_det_64_128")
+    pc, pf = O.init_lcode_params(5), O.init_lcode_params(6)
+    def lmodel(params):
+        m = ref.models.ConditionalBlendshapeLearnableCodeNeRFModel(
+            num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True,
+            num_layers=4, hidden_size=256, include_expression=True)
+        assert list(m.state_dict().keys()) == O.LCODE_KEYS
+        m.load_state_dict(params)
+        return m
+    opt = ref_options(ref, 64, 128, False, 0.0)
+    with torch.no_grad():
+        out_ref = ref.run_one_iter_of_nerf(512, 512, None, lmodel(pc), lmodel(pf), c["ro"], c["rd"], opt, mode="train",
+                                           encode_position_fn=enc_xyz, encode_direction_fn=enc_dir, expressions=c["expr"],
+                                           background_prior=c["bg"], latent_code=c["latent"])
+    out_or = O.render_rays(pc, pf, c["ro"], c["rd"], c["expr"], c["latent"], c["bg"], O.NEAR, O.FAR, 64, 128, mlp=O.lcode_mlp)
+    print("lcode exact:", all(torch.equal(a, b) for a, b in zip(out_ref, out_or)), "w_last range", float(out_ref[6].min()), float(out_ref[6].max()))
+    np.savez_compressed(os.path.join(OUT, "lcode_eval_det_64_128.npz"), **{n: a.numpy() for n, a in zip(names7, out_ref)})
+
     # gradient fixture (reference autograd with the Q9 shim)
     c = C.build_case("train_rand_64_64")
     out_ref, g = run_reference(ref, c, grad=True)

@@ -147,6 +147,49 @@ def paper_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor,
     return torch.cat((rgb, sigma), dim=-1)
 
 
+# --------------------------------------------------------------------------------------
+# second model family: ConditionalBlendshapeLearnableCodeNeRFModel                    (M:529-636)
+# as every config instantiates it: num_layers=4, hidden_size=256, skip_connect_every left at its default 4
+# (the YAML value is never passed, TR:100-109), 10/4 encoding functions, include_input_dir False.
+# --------------------------------------------------------------------------------------
+LCODE_SHAPES = {
+    "layer1.weight": (256, 171), "layers_xyz.0.weight": (256, 256), "layers_xyz.1.weight": (256, 256),
+    "layers_xyz.2.weight": (256, 256), "layers_dir.0.weight": (128, 280), "fc_alpha.weight": (1, 256),
+    "fc_rgb.weight": (3, 128), "fc_feat.weight": (256, 256),
+}
+LCODE_KEYS = [k.replace("weight", p) for k in LCODE_SHAPES for p in ("weight", "bias")]
+
+
+def init_lcode_params(seed: int, dtype=torch.float32, boost: bool = True) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    out: Dict[str, torch.Tensor] = {}
+    for k, shp in LCODE_SHAPES.items():
+        bound = 1.0 / math.sqrt(shp[1])
+        out[k] = ((torch.rand(shp, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+        out[k.replace("weight", "bias")] = ((torch.rand(shp[0], generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
+    if boost:
+        out["fc_alpha.weight"] = out["fc_alpha.weight"] * 300.0
+        out["fc_alpha.bias"] = torch.full_like(out["fc_alpha.bias"], 5.0)
+        out["fc_rgb.weight"] = out["fc_rgb.weight"] * 10.0
+    return out
+
+
+def lcode_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
+    """M:590-636: x = layer1([xyz | expr*1/3 | latent]) (NO activation); 3 x relu(Linear 256); feat = relu(fc_feat(x));
+    alpha = fc_alpha(x) (reads x, not feat); relu(layers_dir.0([feat | dirs])); rgb = fc_rgb."""
+    n = x87.shape[0]
+    xyz, dirs = x87[:, :63], x87[:, 63:]
+    e = (expr * 1 / 3).reshape(1, -1).repeat(n, 1)
+    l = latent.reshape(1, -1).repeat(n, 1)
+    x = _lin(torch.cat((xyz, e, l), dim=1), p, "layer1")
+    for i in range(3):
+        x = torch.relu(_lin(x, p, f"layers_xyz.{i}"))
+    feat = torch.relu(_lin(x, p, "fc_feat"))
+    alpha = _lin(x, p, "fc_alpha")
+    h = torch.relu(_lin(torch.cat((feat, dirs), dim=-1), p, "layers_dir.0"))
+    return torch.cat((_lin(h, p, "fc_rgb"), alpha), dim=-1)
+
+
 def encode_points(ro, rd, z, near: float, far: float, rd_view=None) -> torch.Tensor:
     """run_network's input assembly (T:9-18): pts = ro + rd*z; 'view dirs' = ray_batch[..., -3:] which,
     because the viewdir concat is commented out (T:215-216), is (rd_z, near, far) (Quirk Q1).
@@ -238,12 +281,13 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
 # --------------------------------------------------------------------------------------
 
 def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: float, n_coarse: int, n_fine: int,
-                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None):
+                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None, mlp=None):
     """Coarse pass -> hierarchical resample -> fine pass.  Returns the 7-tuple of T:162
     (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, weights_f[:, -1]).  Random tensors are injected
     (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates."""
     R = ro.shape[0]
     st = stages if stages is not None else {}
+    paper_mlp = mlp if mlp is not None else globals()["paper_mlp"]          # model family (default: the paper model)
     z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype)
     raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far, rd_view), expr, latent).reshape(R, n_coarse, 4).clone()
     st["raw_c_mlp"] = raw.clone()
