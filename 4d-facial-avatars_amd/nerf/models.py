@@ -84,7 +84,7 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
     def hip_backward(self, state, z, d_raw):
         """d_raw -> ([gradients in hip_param_list() order, None for layers_dir.3], d_latent (32))."""
         packed, cond, saved = state
-        return ops.paper_mlp_bwd(self, packed, cond, None, None, z, None, None, None, d_raw, saved)
+        return ops.paper_mlp_bwd(self, packed, cond, z, d_raw, saved)
 
     def forward(self, x, expr=None, latent_code=None, **kwargs):
         raise NotImplementedError(

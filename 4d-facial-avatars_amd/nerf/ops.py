@@ -220,13 +220,9 @@ def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None):
     return raw, (saved,)
 
 
-_PARAM_NUMEL = None
-
-
-def paper_mlp_bwd(model, packed, cond, ro, rd, z, rd_view, expr, latent, d_raw, saved):
+def paper_mlp_bwd(model, packed, cond, z, d_raw, saved):
     """d_raw (n_rays, n_samples, 4) -> ([26 parameter gradients in state_dict order], d_latent (32)).
     layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3)."""
-    global _PARAM_NUMEL
     (saved_t,) = saved
     d_raw = _c(d_raw)
     dev = H.require_device(packed, cond, saved_t, d_raw)

@@ -42,7 +42,6 @@ class _RenderChunk(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, cfg, ro, rd, rd_view, bg, expr, latent, t_rand, noise_c, u, noise_f, n_params_c, *params):
-        params_c, params_f = params[:n_params_c], params[n_params_c:]
         model_c, model_f = cfg["model_coarse"], cfg["model_fine"]
         near, far, nc, nf = cfg["near"], cfg["far"], cfg["num_coarse"], cfg["num_fine"]
         white = cfg["white_background"]

@@ -80,7 +80,7 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
     raw_e = ops.paper_mlp_fwd(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
     assert torch.equal(raw_t, raw_e)                       # training forward == eval forward, bit for bit
     # saved activations against the oracle (spot check: fc_feat output and PE slots that hold raw xyz)
-    grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, None, None, z.to(gpu), None, None, None, d_raw.to(gpu), saved)
+    grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, z.to(gpu), d_raw.to(gpu), saved)
     # ReLU masks as the HIP forward saw them: the oracle's backward is evaluated with the same masks so that the
     # comparison measures the backward arithmetic, not the handful of units whose pre-activation rounds across 0
     n_pts = n_rays * s
