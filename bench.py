@@ -81,7 +81,7 @@ def options(nerf):
                              dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
 
 
-def cpu_baseline(n_rays=1536):
+def cpu_baseline(n_rays=12288):
     """Oracle (CPU port of the reference path) on a bounded sample: n_rays rays of one 512^2 frame, 64+128."""
     from oracle import cases as C
     from oracle import nerface_oracle as O
@@ -199,7 +199,7 @@ def main():
                          "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
-    ap.add_argument("--cpu-rays", type=int, default=1536)
+    ap.add_argument("--cpu-rays", type=int, default=12288)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -279,6 +279,22 @@ def main():
                    "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}",
                    "mlp_precision": args.precision},
     }
+
+    exact = None
+    if args.precision == "bf16x3":
+        # the same frames through the exact-f32 kernels (reported next to the headline, never as `value`)
+        nerf.set_mlp_precision("f32")
+        step(0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(2):
+            step(i % n_frames)
+        torch.cuda.synchronize()
+        exact = (time.perf_counter() - t1) / 2
+        nerf.set_mlp_precision(args.precision)
+    if exact is not None:
+        line["exact_f32"] = {"value": world * H * W / exact, "unit": "rays/s", "ms_per_step": 1e3 * exact,
+                             "note": "same workload on this rank with nerf.set_mlp_precision('f32') (exact-f32 MFMA kernels), 2 frames"}
 
     if rank == 0:
         # ---- roofline of the dominant kernel: fused MLP forward, fine pass of one ray chunk ----------------
