@@ -354,16 +354,7 @@ __global__ void __launch_bounds__(256) k_paper_grad_reduce(const float* __restri
 
 struct NfGradOffsets { int off[NF_PAPER_NUM_PARAMS + 1]; };
 
-// inverse of nfl::pe_slot_to_col: reference PE column (0..62) -> slot
-__device__ __forceinline__ int nf_pe_col_to_slot(int col) {
-    if (col < 3) return 16 * 3 + 4 * 3 + col;                       // raw xyz: chunk 3, group 3, r = col
-    const int q = col - 3, freq = q / 6, rem = q - 6 * freq, sc = rem / 3, comp = rem - 3 * sc;
-    const int pidx = 3 * freq + comp;
-    int g, j, h;
-    if (pidx < 24) { g = pidx >> 3; j = (pidx & 7) >> 1; h = pidx & 1; }
-    else { g = 3; j = (pidx - 24) >> 1; h = (pidx - 24) & 1; }
-    return 16 * j + 4 * g + 2 * h + sc;
-}
+__device__ __forceinline__ int nf_pe_col_to_slot(int col) { return nfl::pe_col_to_slot(col); }
 
 __global__ void __launch_bounds__(256) k_paper_grad_unpack(const float* __restrict__ sum, const float* __restrict__ packed,
                                                            const float* __restrict__ cond, NfGradOffsets offs,

@@ -35,6 +35,7 @@ _PROTOTYPES = {
     "nf_paper_packed_bf16_bytes": (_Z, []),
     "nf_paper_pack_bf16": (C.c_int, [_P, _P, _P]),
     "nf_paper_mlp_fwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_paper_mlp_fwd_train_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_paper_saved_floats": (_Z, [_L]),
     "nf_paper_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_paper_packed_bwd_floats": (_Z, []),

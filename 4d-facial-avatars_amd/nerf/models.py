@@ -75,7 +75,8 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         packed = hw.get()
         cond = ops.paper_condition(packed, expr, latent, near, far)
         if need_grad:
-            raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view)
+            pb = hw.get_bf16() if ops.get_mlp_precision() == "bf16x3" else None
+            raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view, packed_b=pb)
             return raw, (packed, cond, saved)
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None

@@ -23,9 +23,9 @@ PAPER_KEYS = (
 )
 
 
-# Arithmetic of the inference-time MLP GEMMs: "f32" = exact-f32 MFMA (bit-for-bit the training forward);
-# "bf16x3" = split-bf16, three bf16 MFMAs per product with f32 accumulation (~2^-16 relative per layer, 3x faster).
-# Training (anything that needs gradients) always runs the exact-f32 kernels.
+# Arithmetic of the MLP forward GEMMs: "f32" = exact-f32 MFMA; "bf16x3" = split-bf16, three bf16 MFMAs per product with
+# f32 accumulation (~2^-16 relative per layer, 3x faster).  It applies to inference and to the forward of a training step
+# (which then also saves its f32 activations); the backward always runs the exact-f32 kernels.
 _VALID_PRECISIONS = ("f32", "bf16x3")
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
 
@@ -207,16 +207,22 @@ def paper_mlp_fwd_bf16(packed_b, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
     return raw
 
 
-def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None):
-    """Training forward: returns (raw, (saved,)) where `saved` holds every layer output for the backward."""
+def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):
+    """Training forward: returns (raw, (saved,)) where `saved` holds every layer output for the backward.
+    packed_b given -> the forward runs on the split-bf16 kernel (the backward is always exact f32)."""
     dev = H.require_device(packed, cond, ro, rd, z, rd_view)
     n_rays, n_samples = z.shape
     lib = H.lib()
     raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
     saved = torch.empty(lib.nf_paper_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        H.check(lib.nf_paper_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
-                                           n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_paper_mlp_fwd_train")
+        if packed_b is not None:
+            H.check(lib.nf_paper_mlp_fwd_train_bf16(H.ptr(packed_b), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                                    n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
+                    "nf_paper_mlp_fwd_train_bf16")
+        else:
+            H.check(lib.nf_paper_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                               n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_paper_mlp_fwd_train")
     return raw, (saved,)
 
 

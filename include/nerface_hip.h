@@ -79,6 +79,11 @@ int nf_paper_pack_bf16(const float* const* params, void* packed_bf16, nf_stream_
 int nf_paper_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
                           const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                           nf_stream_t stream);
+/* training forward on the split-bf16 kernel: also fills `saved` (f32, same layout as nf_paper_mlp_fwd_train); the
+ * backward (nf_paper_mlp_bwd) stays on the exact-f32 kernels.                                                */
+int nf_paper_mlp_fwd_train_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
+                                const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                                float* saved, nf_stream_t stream);
 
 /* ---- K4 training path ---------------------------------------------------------------------------------
  * The reference trains through autograd (train_transformed_rays.py:389); here the forward saves every layer

@@ -64,6 +64,29 @@ def _oracle_mlp_grads(p, ro, rd, z, expr, latent, d_raw, masks=None, dtype=torch
 
 
 @pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
+def test_bf16x3_training_forward_saves_match_f32(hip_lib, gpu, n_rays, s):
+    """The split-bf16 training forward must fill the `saved` buffer (all sections, same layout) like the exact-f32 one."""
+    import nerf
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    g = torch.Generator().manual_seed(17)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 9, n_rays, 17)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    m = U.make_model(nerf, c["p_fine"], gpu)
+    hw = m.hip_weights()
+    cond = ops.paper_condition(hw.get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    raw_f, (sv_f,) = ops.paper_mlp_fwd_train(hw.get(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
+    raw_b, (sv_b,) = ops.paper_mlp_fwd_train(hw.get(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu), packed_b=hw.get_bf16())
+    n_pts = n_rays * s
+    for name in SAVED:
+        a, b = saved_section(sv_f.cpu(), name, n_pts), saved_section(sv_b.cpu(), name, n_pts)
+        d = float((a - b).abs().max())
+        assert d <= 3e-4 * (1 + float(a.abs().max())), (name, d)
+    assert torch.equal(saved_section(sv_f.cpu(), "dirf", n_pts), saved_section(sv_b.cpu(), "dirf", n_pts))
+    assert float((raw_f - raw_b).abs().max()) < 3e-4 * (1 + float(raw_f.abs().max()))
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
 def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
     import nerf
     from nerf import ops
