@@ -156,6 +156,20 @@ int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float*
                       int64_t n_rays, int n_coarse, int n_fine, float* z_samples /* (R,n_fine) or NULL */,
                       float* z_fine /* (R,n_coarse+n_fine) */, nf_stream_t stream);
 
+/* ---- whole per-chunk inference pipeline -- replaces predict_and_render_radiance (T:36-162) in eval: coarse depths,
+ *      coarse MLP, integrator, resampling, fine MLP, integrator, 7-tuple (T:162), paper model.  One call, caller-provided
+ *      workspace (nf_render_rays_workspace_floats), kernels enqueued on `stream`.  packed_bf16_* non-NULL selects the
+ *      split-bf16 MLP kernel for that network.  n_fine = 0: coarse only (fine outputs untouched, w_last from the coarse pass).
+ *      t_vals: linspace(0,1,n_coarse) table; t_rand / noise_* NULL = off; u as in nf_sample_pdf.                         */
+size_t nf_render_rays_workspace_floats(int64_t n_rays, int n_coarse, int n_fine);
+int nf_render_rays_fwd(const float* packed_coarse, const void* packed_bf16_coarse, const float* packed_fine,
+                       const void* packed_bf16_fine, const float* expr76, const float* latent32, const float* ro,
+                       const float* rd, const float* rd_view, const float* bg, const float* t_vals, const float* t_rand,
+                       const float* u, int64_t u_row_stride, const float* noise_coarse, const float* noise_fine,
+                       int64_t n_rays, int n_coarse, int n_fine, float near_z, float far_z, int white_background,
+                       float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
+                       float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
+
 /* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
 int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);
 

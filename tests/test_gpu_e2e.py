@@ -155,3 +155,36 @@ def test_white_background(hip_lib, gpu):
     assert (rgb.cpu().double() - rgb_o.detach()).abs().max() < 5e-6
     d_raw = ops.volume_render_bwd(f(raw), f(z), f(rd), None, None, f(d_rgb), True)
     assert float((d_raw.cpu().double() - raw_l.grad).norm() / raw_l.grad.norm()) < 2e-5
+
+
+@pytest.mark.parametrize("split", [False, True])
+def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
+    """nf_render_rays_fwd (one C call per ray chunk) must reproduce the Python-sequenced kernels bit for bit."""
+    import nerf
+    from nerf import _hip as H
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    nerf.set_mlp_precision("bf16x3" if split else "f32")
+    try:
+        out_py, mc, mf, _ = U.run_product(nerf, c, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+    n, nc, nf = c["n_rays"], 64, 64
+    lib = H.lib()
+    dv = lambda t: None if t is None else t.to(gpu).float().contiguous()
+    ws_n = lib.nf_render_rays_workspace_floats(n, nc, nf)
+    ws = torch.empty(ws_n, device=gpu)
+    outs = [torch.empty((n, 3), device=gpu), torch.empty(n, device=gpu), torch.empty(n, device=gpu), torch.empty((n, 3), device=gpu),
+            torch.empty(n, device=gpu), torch.empty(n, device=gpu), torch.empty(n, device=gpu)]
+    hc, hf = mc.hip_weights(), mf.hip_weights()
+    t_vals = ops.linspace01(nc, gpu)
+    args = [hc.get(), hc.get_bf16() if split else None, hf.get(), hf.get_bf16() if split else None, dv(c["expr"]), dv(c["latent"]),
+            dv(c["ro"]), dv(c["rd"]), None, dv(c["bg"]), t_vals, dv(c["t_rand"])]
+    u, noise_c, noise_f = dv(c["u"]), dv(c["noise_c"]), dv(c["noise_f"])      # keep references: raw pointers do not own memory
+    rc = lib.nf_render_rays_fwd(*[H.ptr(a) for a in args], H.ptr(u), nf, H.ptr(noise_c), H.ptr(noise_f), n, nc, nf,
+                                float(np.float32(O.NEAR)), float(np.float32(O.FAR)), 0, H.ptr(ws), ws_n, *[H.ptr(o) for o in outs],
+                                H.stream_ptr(gpu))
+    assert rc == 0
+    torch.cuda.synchronize()
+    for k, (a, b) in enumerate(zip(out_py, outs)):
+        assert torch.equal(a, b), (k, float((a - b).abs().max()))
