@@ -74,8 +74,8 @@ def frame_pose(f):
     return torch.tensor(m, dtype=torch.float32)
 
 
-def options(nerf):
-    mode = dict(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=CHUNK, perturb=True, lindisp=False,
+def options(nerf, chunk=CHUNK):
+    mode = dict(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=chunk, perturb=True, lindisp=False,
                 radiance_field_noise_std=0.0, white_background=False)
     return nerf.CfgNode(dict(nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode)),
                              dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
@@ -197,6 +197,7 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
                     help="inference GEMM arithmetic: bf16x3 = split-bf16 (3 bf16 MFMAs per product, f32 accumulate; passes the "
                          "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
+    ap.add_argument("--chunksize", type=int, default=CHUNK, help="validation ray chunk (shipped configs: 65536)")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=12288)
@@ -227,7 +228,7 @@ def main():
     model_c, model_f = synth_params(0, dev), synth_params(1, dev)
     if args.mode == "train":
         return bench_train(args, nerf, model_c, model_f, dev, rank, world, dist)
-    opt = options(nerf)
+    opt = options(nerf, args.chunksize)
     enc_xyz = nerf.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
     enc_dir = nerf.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
     g = torch.Generator().manual_seed(7)

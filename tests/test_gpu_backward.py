@@ -199,3 +199,52 @@ def test_adam_step_moves_live_parameters(hip_lib, gpu):
         losses.append(float(loss))
     assert all(np.isfinite(losses))
     assert losses[-1] < losses[0]                    # 3 Adam steps on the same rays/target reduce the loss
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_training_trajectory_follows_oracle(hip_lib, gpu, precision):
+    """Eight Adam steps (coarse+fine, perturb + density noise, latent regulariser) on the HIP path and on the CPU oracle with
+    identical data and random draws: the loss trajectories must coincide.  (Adam normalises tiny gradients, so parameters
+    are compared through the loss they produce, not element-wise.)"""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    n, nc, nf = c["n_rays"], 64, 64
+    # --- oracle side (fp32 autograd on CPU)
+    pc = {k: v.clone().requires_grad_(True) for k, v in c["p_coarse"].items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in c["p_fine"].items()}
+    lat_o = torch.zeros(32, requires_grad=True)
+    opt_o = torch.optim.Adam(list(pc.values()) + list(pf.values()) + [lat_o], lr=5e-4)
+    # --- product side
+    mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+    lat_h = torch.zeros(32, device=gpu, requires_grad=True)
+    opt_h = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()) + [lat_h], lr=5e-4)
+    o = U.make_options(nerf, nc, nf, True, 0.1)
+    ex, ed = U.encoders(nerf)
+    nerf.set_mlp_precision(precision)
+    losses_o, losses_h = [], []
+    try:
+        for it in range(8):
+            t_rand, noise_c, u, noise_f = C.randoms(n, nc, nf, seed=500 + it)
+            out = O.render_rays(pc, pf, c["ro"], c["rd"], c["expr"], lat_o, c["bg"], O.NEAR, O.FAR, nc, nf, t_rand=t_rand,
+                                noise_c=noise_c * 0.1, u=u, noise_f=noise_f * 0.1)
+            lo = O.train_loss(out[0], out[3], c["tgt"], lat_o)
+            opt_o.zero_grad()
+            lo.backward()
+            opt_o.step()
+            losses_o.append(float(lo.detach()))
+            with U.injected_random([t_rand, u], [noise_c, noise_f]):
+                outh = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), o, mode="train",
+                                                 encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                                 background_prior=c["bg"].to(gpu), latent_code=lat_h)
+            lh = O.train_loss(outh[0], outh[3], c["tgt"].to(gpu), lat_h)
+            opt_h.zero_grad()
+            lh.backward()
+            opt_h.step()
+            losses_h.append(float(lh.detach()))
+    finally:
+        nerf.set_mlp_precision("f32")
+    print(precision, "oracle losses", [f"{v:.6f}" for v in losses_o])
+    print(precision, "HIP    losses", [f"{v:.6f}" for v in losses_h])
+    assert losses_o[-1] < losses_o[0]
+    for a, b in zip(losses_o, losses_h):
+        assert abs(a - b) <= 2e-4 * abs(a) + 1e-6, (losses_o, losses_h)
