@@ -72,6 +72,7 @@ static void nf_build_gather_table(std::vector<uint32_t>& t) {
                       return r < 2 ? 256 + 6 * g + 3 * r : -1;
                   },
                   /*alpha_row=*/128);
+    nf_fill_layer(t, OFF_D0E, 18, 9, ID_DIR0_W, 128, 280, [](int s) { return s < 280 ? s : -1; }, /*alpha_row=*/128);
     nf_fill_layer(t, OFF_D1, 8, 8, 18, 128, 128, ident);
     nf_fill_layer(t, OFF_D2, 8, 8, 20, 128, 128, ident);
     nf_fill_layer(t, OFF_RGB, 8, 1, ID_RGB_W, 3, 128, ident);

@@ -52,7 +52,10 @@ constexpr int BIAS_FLOATS = B_RGB + 16;         // 2208 (the bias table proper)
 constexpr int B_CVEC = BIAS_FLOATS;             // cond only: [expr*1/3 (76) | latent (32)] as the kernels used it
 constexpr int B_DVEC = B_CVEC + NCOND;          // cond only: PE4 of (near, far): index 4f + 2sc + (0: near, 1: far)
 constexpr int COND_FLOATS = B_DVEC + 16;        // 2332
-constexpr int PACKED_FLOATS = OFF_BIAS + BIAS_FLOATS;
+// layers_dir.0 for PRE-ENCODED inputs (model.forward(x87, ...), nf_mlp_encoded.hip): 16 feat chunks + 2 chunks holding the
+// 24 reference direction columns 256..279 in reference order (slot 256 + s <-> column 256 + s, s < 24), 9 tiles as OFF_D0.
+constexpr int OFF_D0E = OFF_BIAS + BIAS_FLOATS;
+constexpr int PACKED_FLOATS = OFF_D0E + 18 * 9 * FRAG;
 
 // ---- training: activations saved by the forward, floats per point ---------------------------------------
 // Section X of a buffer for n points starts at X * n and is an [n][width] row-major matrix.

@@ -32,6 +32,7 @@ _PROTOTYPES = {
     "nf_paper_pack": (C.c_int, [_P, _P, _P]),
     "nf_paper_condition": (C.c_int, [_P, _P, _P, _F, _F, _P, _P]),
     "nf_paper_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_paper_forward_encoded": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "nf_paper_packed_bf16_bytes": (_Z, []),
     "nf_paper_pack_bf16": (C.c_int, [_P, _P, _P]),
     "nf_paper_mlp_fwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),

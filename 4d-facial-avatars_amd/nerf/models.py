@@ -88,10 +88,28 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         return ops.paper_mlp_bwd(self, packed, cond, z, d_raw, saved)
 
     def forward(self, x, expr=None, latent_code=None, **kwargs):
-        raise NotImplementedError(
-            "ConditionalBlendshapePaperNeRFModel.forward on pre-encoded (N, 87) inputs is not part of the MI355X hot "
-            "path: call nerf.run_one_iter_of_nerf(...), which evaluates the network inside the fused HIP kernel "
-            "(positional encoding included) exactly as train_transformed_rays.py / eval_transformed_rays.py do.")
+        """M:236-261 on pre-encoded inputs x (N, 87) = [PE10(xyz) | PE4(dirs)] -> (N, 4), as run_network calls it (T:20-24).
+        Inference only (kernel nf_paper_forward_encoded); training goes through run_one_iter_of_nerf, whose fused kernels
+        own the backward."""
+        from . import _hip as H
+        if not self.fused_supported() or expr is None or latent_code is None:
+            raise NotImplementedError("forward() is built for the NeRFace geometry and needs expr and latent_code")
+        if torch.is_grad_enabled() and (x.requires_grad or latent_code.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("ConditionalBlendshapePaperNeRFModel.forward has no autograd on the MI355X build: train through "
+                                      "nerf.run_one_iter_of_nerf(...), or call forward under torch.no_grad()")
+        x = ops._c(x.detach())
+        if x.dim() != 2 or x.shape[1] != 87:
+            raise ValueError("expected pre-encoded inputs of shape (N, 87)")
+        expr_d, lat_d = ops._c(expr.detach()).reshape(-1), ops._c(latent_code.detach()).reshape(-1)
+        packed = self.hip_weights().get()
+        dev = H.require_device(packed, x, expr_d, lat_d)
+        lib = H.lib()
+        cond = torch.empty(lib.nf_paper_cond_floats(), dtype=torch.float32, device=dev)
+        out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_paper_forward_encoded(H.ptr(packed), H.ptr(x), H.ptr(expr_d), H.ptr(lat_d), x.shape[0], H.ptr(cond),
+                                                 H.ptr(out), H.stream_ptr(dev)), "nf_paper_forward_encoded")
+        return out
 
 
 LCODE_KEYS = [f"{n}.{p}" for n in ("layer1", "layers_xyz.0", "layers_xyz.1", "layers_xyz.2", "layers_dir.0", "fc_alpha", "fc_rgb", "fc_feat")

@@ -26,10 +26,24 @@ from .volume_rendering_utils import volume_render_radiance_field  # noqa: F401  
 
 
 def run_network(network_fn, pts, ray_batch, chunksize, embed_fn, embeddirs_fn, expressions=None, latent_code=None):
-    """T:9-33.  The unfused form (encode -> concat -> chunked MLP calls) is what the fused kernel replaces;
-    it is not offered as a separate product path."""
-    raise NotImplementedError("run_network is fused into nf_paper_mlp_fwd; call run_one_iter_of_nerf / "
-                              "predict_and_render_radiance instead")
+    """T:9-33, the unfused form: encode points and "view directions" (= ray_batch[..., -3:], Quirk Q1), concatenate, evaluate
+    the model in point chunks, reshape.  Kept for API compatibility (inference; kernels K3 + nf_paper_forward_encoded);
+    run_one_iter_of_nerf does all of this inside one fused kernel without materialising the encodings."""
+    pts_flat = pts.reshape((-1, pts.shape[-1]))
+    embedded = embed_fn(pts_flat)
+    if embeddirs_fn is not None:
+        viewdirs = ray_batch[..., None, -3:]
+        input_dirs_flat = viewdirs.expand(pts.shape).reshape((-1, 3))
+        embedded = torch.cat((embedded, embeddirs_fn(input_dirs_flat.contiguous())), dim=-1)
+    batches = get_minibatches(embedded, chunksize=chunksize)
+    if expressions is None:
+        preds = [network_fn(batch) for batch in batches]
+    elif latent_code is not None:
+        preds = [network_fn(batch, expressions, latent_code) for batch in batches]
+    else:
+        preds = [network_fn(batch, expressions) for batch in batches]
+    radiance_field = torch.cat(preds, dim=0)
+    return radiance_field.reshape(list(pts.shape[:-1]) + [radiance_field.shape[-1]])
 
 
 # --------------------------------------------------------------------------------------------------

@@ -71,6 +71,12 @@ int nf_paper_mlp_fwd(const float* packed, const float* cond, const float* ro, co
                      const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                      nf_stream_t stream);
 
+/* ---- ConditionalBlendshapePaperNeRFModel.forward on pre-encoded inputs (M:236-261 as run_network calls it, T:20-24):
+ * x87 (n_points, 87) = [PE10(xyz) | PE4(dirs)], expr (76), latent (32) -> out (n_points, 4).  Inference; `cond` is scratch
+ * of nf_paper_cond_floats() floats.  The hot path never builds x87 (nf_paper_mlp_fwd encodes in registers).            */
+int nf_paper_forward_encoded(const float* packed, const float* x87, const float* expr76, const float* latent32,
+                             int64_t n_points, float* cond, float* out, nf_stream_t stream);
+
 /* ---- K4, split-bf16 variant (eval): every GEMM as 3 bf16 MFMAs (W_hi x_hi + W_hi x_lo + W_lo x_hi) with f32
  * accumulation -- ~2^-16 relative per layer instead of 2^-24, 3x the throughput of the exact-f32 matrix rate.
  * Same arguments/semantics as nf_paper_mlp_fwd; `cond` is the same table (from the f32 image).              */

@@ -140,3 +140,29 @@ def test_resample_merge(hip_lib, gpu):
     assert torch.all(z_f[:, 1:] >= z_f[:, :-1])
     d = (z_f.cpu() - st["z_f"]).abs()
     assert float((d < 1e-5).float().mean()) > 0.99
+
+
+def test_model_forward_and_run_network_on_encoded_inputs(hip_lib, gpu):
+    """model(x87, expr, latent) and nerf.run_network (the reference's unfused call chain, T:9-33) against the oracle."""
+    import nerf
+    from tests import util as U
+    c, ro, rd, z = _mlp_inputs(6, 37, 8)
+    p = c["p_coarse"]
+    m = U.make_model(nerf, p, gpu)
+    x87 = O.encode_points(ro, rd, z, O.NEAR, O.FAR)
+    with torch.no_grad():
+        out = m(x87.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu)).cpu()
+    p64 = {k: v.double() for k, v in p.items()}
+    ref = O.paper_mlp(p64, x87.double(), c["expr"].double(), c["latent"].double())
+    scale = ref.abs().amax(dim=0)
+    assert torch.all((out.double() - ref).abs().amax(dim=0) <= 2e-5 * scale + 2e-5)
+    # run_network: same call as the reference's predict_and_render_radiance makes (T:84-93)
+    ex, ed = U.encoders(nerf)
+    pts = (ro[:, None, :] + rd[:, None, :] * z[:, :, None]).to(gpu)
+    ray_batch = torch.cat((ro, rd, torch.full((6, 1), O.NEAR), torch.full((6, 1), O.FAR)), dim=-1).to(gpu)
+    with torch.no_grad():
+        rf = nerf.run_network(m, pts, ray_batch, 100, ex, ed, c["expr"].to(gpu), c["latent"].to(gpu)).cpu()
+    assert rf.shape == (6, 37, 4)
+    assert torch.all((rf.reshape(-1, 4).double() - ref).abs().amax(dim=0) <= 3e-5 * scale + 3e-5)
+    with pytest.raises(NotImplementedError):
+        m(x87.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu).requires_grad_(True))

@@ -89,7 +89,9 @@ def test_product_has_no_cpu_path():
         nerf.positional_encoding(torch.zeros(3, 3), 10, True)
     m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_dir=False)
     with pytest.raises(NotImplementedError):
-        m(torch.zeros(2, 87), torch.zeros(76), torch.zeros(32))
+        m(torch.zeros(2, 87), torch.zeros(76), torch.zeros(32))               # grad mode: no autograd through forward()
+    with torch.no_grad(), pytest.raises(RuntimeError):
+        m(torch.zeros(2, 87), torch.zeros(76), torch.zeros(32))               # CPU tensors: no CPU path
 
 
 def test_cfgnode_roundtrip():
