@@ -105,10 +105,28 @@ def cpu_baseline(n_rays=12288):
                 best, best_t = nt, t
         torch.set_num_threads(best)
         t0 = time.perf_counter()
-        C.run_oracle(c)
+        ref = C.run_oracle(c)
         dt = time.perf_counter() - t0
+    # parity of the product on exactly this sample (same rays, weights, conditioning; deterministic sampling): the
+    # north-star gate |PSNR(ours, target) - PSNR(reference algorithm, target)| <= 1e-4 dB, in both precisions
+    parity = {}
+    try:
+        import nerf
+        from tests import util as U
+        tgt = C.ray_subset(H, W, 3, n_rays, seed=5)[3]
+        keep = nerf.get_mlp_precision()
+        for prec in ("bf16x3", "f32"):
+            nerf.set_mlp_precision(prec)
+            out, *_ = U.run_product(nerf, c, torch.device("cuda", torch.cuda.current_device()))
+            parity[prec] = {"abs_dpsnr_db_fine": abs(O.psnr(out[3].cpu(), tgt) - O.psnr(ref[3], tgt)),
+                            "abs_dpsnr_db_coarse": abs(O.psnr(out[0].cpu(), tgt) - O.psnr(ref[0], tgt)),
+                            "self_psnr_db_fine": O.psnr(out[3].cpu(), ref[3])}
+        nerf.set_mlp_precision(keep)
+    except Exception as e:                                    # the baseline number must not depend on this extra
+        parity = {"error": repr(e)}
     return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s"}
+            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s",
+            "parity_on_sample": parity}
 
 
 def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):

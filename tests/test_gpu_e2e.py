@@ -188,3 +188,21 @@ def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
     torch.cuda.synchronize()
     for k, (a, b) in enumerate(zip(out_py, outs)):
         assert torch.equal(a, b), (k, float((a - b).abs().max()))
+
+
+def test_no_background_prior(hip_lib, gpu):
+    """background_prior=None (vanilla compositing: last colour through the sigmoid, T:95 skipped) end to end vs the oracle."""
+    import nerf
+    c = C.build_case("eval_det_64_128")
+    c["bg"] = None
+    ref = C.run_oracle(c)
+    mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+    opt = U.make_options(nerf, 64, 128, False, 0.0)
+    ex, ed = U.encoders(nerf)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                        background_prior=None, latent_code=c["latent"].to(gpu))
+    for n, a, b in zip(NAMES7, out, ref):
+        d = float((a.cpu() - b).abs().max())
+        assert d <= TOL[n], (n, d)
