@@ -444,11 +444,16 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
 
 static std::once_flag g_jobs_once[64];
 
-extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved,
-                                const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
-                                float* grads, nf_stream_t stream) {
+// defined in nf_mlp_bf16_bwd.hip
+int nfb_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                         nf_stream_t stream);
+
+static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const float* cond, const float* saved,
+                       const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
+                       nf_stream_t stream) {
     using namespace nfl;
-    if (!packed || !packed_t || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0) return NF_EINVAL;
+    if (!packed || (!packed_t && !packed_t_bf16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0)
+        return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
     int dev = 0;
@@ -475,8 +480,13 @@ extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, cons
     if (grid > 0x7fffffff) return NF_EINVAL;
     e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
-                       n_points, dz);
+    if (packed_t_bf16) {
+        const int rc2 = nfb_launch_bwd_chain(packed_t_bf16, saved, d_raw, n_points, dz, stream);
+        if (rc2) return rc2;
+    } else {
+        hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
+                           n_points, dz);
+    }
     hipLaunchKernelGGL(k_paper_dw_gemm, dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, dz, d_raw, saved, n_points, pps, slabs);
     hipLaunchKernelGGL(k_paper_grad_reduce, dim3(512), dim3(256), 0, s, slabs, ns, sum);
     NfGradOffsets offs;
@@ -484,4 +494,20 @@ extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, cons
     for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];
     hipLaunchKernelGGL(k_paper_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved,
+                                const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                float* grads, nf_stream_t stream) {
+    if (!packed_t) return NF_EINVAL;
+    return nf_bwd_impl(packed, packed_t, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+}
+
+// Same, with the dX chain on the split-bf16 kernel (nf_mlp_bf16_bwd.hip).  `saved` must come from nf_paper_mlp_fwd_train_bf16
+// (it carries the ReLU bit masks); the weight-gradient GEMMs and the reduction are the exact-f32 ones.
+extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
+                                     const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                     float* grads, nf_stream_t stream) {
+    if (!packed_t_bf16) return NF_EINVAL;
+    return nf_bwd_impl(packed, nullptr, packed_t_bf16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
 }

@@ -64,7 +64,10 @@ constexpr int S_H0 = 64, S_H1 = 320, S_H2 = 576, S_H3 = 832, S_H4 = 1088, S_H5 =
 constexpr int S_FEAT = 1600;                     // 256, fc_feat output
 constexpr int S_D0 = 1856, S_D1 = 1984, S_D2 = 2112;                                     // 128 each, post-ReLU
 constexpr int S_DIRF = 2240;                     // 16, dir slot order: (sin, cos, 0, 0)(rd_z 2^g), g = 0..3
-constexpr int SAVED_PER_POINT = 2256;
+constexpr int S_MASK = 2256;                     // split-bf16 training forward only: ReLU bit masks, 9 layers (h0..h5, layers_dir.0..2)
+                                                 // x [n points] x [2 lane halves] x 4 dwords; bit 16 nt + r of half h <-> feature
+                                                 // 32 nt + (r&3) + 8 (r>>2) + 4 h  (the D-register order of the bf16 kernels)
+constexpr int SAVED_PER_POINT = 2256 + 9 * 8;
 // ---- training: pre-activation gradients written by the backward chain, floats per point ------------------
 constexpr int Z_L0 = 0, Z_L1 = 256, Z_L2 = 512, Z_L3 = 768, Z_L4 = 1024, Z_L5 = 1280, Z_FEAT = 1536;
 constexpr int Z_D0 = 1792, Z_D1 = 1920, Z_D2 = 2048;

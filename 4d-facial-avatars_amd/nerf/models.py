@@ -77,15 +77,15 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         if need_grad:
             pb = hw.get_bf16() if ops.get_mlp_precision() == "bf16x3" else None
             raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view, packed_b=pb)
-            return raw, (packed, cond, saved)
+            return raw, (packed, cond, saved, pb is not None)
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
         return ops.paper_mlp_fwd(packed, cond, ro, rd, z, rd_view), None
 
     def hip_backward(self, state, z, d_raw):
         """d_raw -> ([gradients in hip_param_list() order, None for layers_dir.3], d_latent (32))."""
-        packed, cond, saved = state
-        return ops.paper_mlp_bwd(self, packed, cond, z, d_raw, saved)
+        packed, cond, saved, split = state
+        return ops.paper_mlp_bwd(self, packed, cond, z, d_raw, saved, split=split)
 
     def forward(self, x, expr=None, latent_code=None, **kwargs):
         """M:236-261 on pre-encoded inputs x (N, 87) = [PE10(xyz) | PE4(dirs)] -> (N, 4), as run_network calls it (T:20-24).

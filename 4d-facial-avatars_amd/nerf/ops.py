@@ -128,6 +128,8 @@ class PaperWeights:
         self._versions_t = None
         self.packed_b = None            # (hi, lo) bf16 stream for the split-bf16 forward (lazily built)
         self._versions_b = None
+        self.packed_bt = None           # transposed (hi, lo) bf16 stream for the split-bf16 backward chain
+        self._versions_bt = None
 
     def get_t(self) -> torch.Tensor:
         """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
@@ -142,6 +144,19 @@ class PaperWeights:
                 H.check(lib.nf_paper_pack_bwd(arr, H.ptr(self.packed_t), H.stream_ptr(dev)), "nf_paper_pack_bwd")
             self._versions_t = sig
         return self.packed_t
+
+    def get_bf16_t(self) -> torch.Tensor:
+        sig = self._signature()
+        if self.packed_bt is None or sig != self._versions_bt:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed_bt is None or self.packed_bt.device != dev:
+                self.packed_bt = torch.empty(lib.nf_paper_packed_bwd_bf16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack_bwd_bf16(arr, H.ptr(self.packed_bt), H.stream_ptr(dev)), "nf_paper_pack_bwd_bf16")
+            self._versions_bt = sig
+        return self.packed_bt
 
     def get_bf16(self) -> torch.Tensor:
         sig = self._signature()
@@ -226,21 +241,27 @@ def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):
     return raw, (saved,)
 
 
-def paper_mlp_bwd(model, packed, cond, z, d_raw, saved):
+def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False):
     """d_raw (n_rays, n_samples, 4) -> ([26 parameter gradients in state_dict order], d_latent (32)).
-    layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3)."""
+    layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3).  split=True runs the dX chain on the
+    split-bf16 kernel (requires `saved` from the split-bf16 training forward); dW/db stay exact f32."""
     (saved_t,) = saved
     d_raw = _c(d_raw)
     dev = H.require_device(packed, cond, saved_t, d_raw)
     lib = H.lib()
     n_rays, n_samples = z.shape
-    packed_t = model.hip_weights().get_t()
     ws_floats = lib.nf_paper_bwd_workspace_floats(n_rays * n_samples)
     ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
     flat = torch.empty(lib.nf_paper_grad_floats(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        H.check(lib.nf_paper_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
-                                     n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd")
+        if split:
+            packed_bt = model.hip_weights().get_bf16_t()
+            H.check(lib.nf_paper_mlp_bwd_bf16(H.ptr(packed), H.ptr(packed_bt), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
+                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd_bf16")
+        else:
+            packed_t = model.hip_weights().get_t()
+            H.check(lib.nf_paper_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
+                                         n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd")
     params = model.hip_param_list()
     grads, off = [], 0
     for i, p in enumerate(params):

@@ -86,8 +86,9 @@ def test_bf16x3_training_forward_saves_match_f32(hip_lib, gpu, n_rays, s):
     assert float((raw_f - raw_b).abs().max()) < 3e-4 * (1 + float(raw_f.abs().max()))
 
 
+@pytest.mark.parametrize("split", [False, True])
 @pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
-def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
+def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s, split):
     import nerf
     from nerf import ops
     c = C.build_case("train_rand_64_64")
@@ -99,11 +100,12 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
     m = U.make_model(nerf, p, gpu)
     pk = m.hip_weights().get()
     cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
-    raw_t, saved = ops.paper_mlp_fwd_train(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
-    raw_e = ops.paper_mlp_fwd(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
+    raw_t, saved = ops.paper_mlp_fwd_train(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu), packed_b=m.hip_weights().get_bf16() if split else None)
+    raw_e = (ops.paper_mlp_fwd_bf16(m.hip_weights().get_bf16(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu)) if split
+             else ops.paper_mlp_fwd(pk, cond, ro.to(gpu), rd.to(gpu), z.to(gpu)))
     assert torch.equal(raw_t, raw_e)                       # training forward == eval forward, bit for bit
     # saved activations against the oracle (spot check: fc_feat output and PE slots that hold raw xyz)
-    grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, z.to(gpu), d_raw.to(gpu), saved)
+    grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, z.to(gpu), d_raw.to(gpu), saved, split=split)
     # ReLU masks as the HIP forward saw them: the oracle's backward is evaluated with the same masks so that the
     # comparison measures the backward arithmetic, not the handful of units whose pre-activation rounds across 0
     n_pts = n_rays * s
@@ -115,7 +117,7 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
     flips = 0
     for name, a_free in zip(order, acts_free):
         got = saved_section(sv, name, n_pts)
-        assert (got.double() - a_free).abs().max() < 1e-4 * (1 + float(a_free.detach().abs().max())), name     # saved activations
+        assert (got.double() - a_free).abs().max() < 3e-4 * (1 + float(a_free.detach().abs().max())), name     # saved activations
         if name != "feat":
             flips += int(((got > 0) != (a_free > 0)).sum())
     print(f"ReLU mask flips vs fp64 oracle: {flips} of {sum(mk.numel() for mk in masks)}")
@@ -128,10 +130,10 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s):
             continue
         e = rel_l2(gh.cpu(), go)
         worst = max(worst, e)
-        assert e < 1e-4, (k, e)
+        assert e < (3e-4 if split else 1e-4), (k, e)      # split: forward activations AND the dX chain carry 2^-16 roundings
     e = rel_l2(g_lat.cpu(), lat.grad)
-    print(f"mlp bwd ({n_rays}x{s}): worst param rel L2 {worst:.2e}, latent {e:.2e}")
-    assert e < 1e-4
+    print(f"mlp bwd ({n_rays}x{s}, split={split}): worst param rel L2 {worst:.2e}, latent {e:.2e}")
+    assert e < (3e-4 if split else 1e-4)
 
 
 def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
