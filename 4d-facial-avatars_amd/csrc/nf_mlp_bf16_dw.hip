@@ -1,0 +1,319 @@
+// B2, split-bf16 variant: the weight-gradient GEMMs  dW = dZ^T . X  on the bf16 matrix pipe at fp32-class accuracy.
+//
+// Same inputs and outputs as k_paper_dw_gemm (nf_mlp_bwd.hip): dZ sections [n_points][width] written by the backward
+// chain, d_raw [n_points][4], the activations saved by the training forward, and per-slice 594k-float slabs of partial
+// dW / column sums that B3 reduces.  What changes is the arithmetic and the data movement:
+//   * every operand value x is split into bf16 (hi, lo) and each 32x32 output tile takes three
+//     v_mfma_f32_32x32x16_bf16 per 16 points (hi.hi + hi.lo + lo.hi, f32 accumulate) instead of sixteen f32 MFMAs;
+//   * at that rate the kernel is HBM-bound (every dZ / activation byte has to be read once: 17.7 KB per point), so a
+//     WORKGROUP (16 waves) owns a whole 256 x 256 product -- or a bundle of smaller ones with a similar byte count --
+//     and reads each operand ONCE per point; each wave keeps a 64 x 64 block of the output in 64 accumulators
+//     (4 waves per SIMD, 128 registers each);
+//   * software pipeline over 16-point stages (one MFMA k-step), one workgroup barrier per stage:
+//       L(i+2)  each wave loads the raw f32 values of "its" 32-feature operand tile straight into registers, already
+//               transposed: lane (h, c) reads feature c of points 8 h .. 8 h + 7 (8 dword loads, two full 128-byte
+//               lines per wave instruction); two stages (64 KB per CU) stay in flight, which is what it takes to
+//               keep HBM busy -- tails and narrow sections are zero-filled here,
+//       C(i)    the tile is split ONCE into the MFMA fragment pair (hi, lo) and written to LDS lane-linearly
+//               (the MFMA contraction index is the point); bias gradients (column sums of dZ) are accumulated here
+//               in f32,
+//       M(i-1)  2 + 2 fragment pairs per wave (conflict-free ds_read_b128), 12 MFMAs, branch-free.
+#include <mutex>
+
+#include "nf_mlp_bf16_common.h"
+
+struct NfbDwSeg {
+    int kind;      // 0: dz section, 1: d_raw, 2: saved section
+    int sec;       // section offset (floats per point)
+    int width;     // floats per point
+};
+struct NfbDwTile {   // one 32-feature operand tile of a stage
+    int seg, f0;     // segment, first feature
+    int cs_off;      // >= 0: slab offset of the column sums of these features (bias gradients)
+};
+struct NfbDwProd {   // one wave: (na <= 2 row tiles of dZ) x (nb <= 2 column tiles of activations), consecutive tile ids
+    int na, nb, a_tile, b_tile;
+    int a_valid, b_valid;           // valid rows / columns (narrow sections)
+    int out_off, ldo;               // slab offset of (row 0, column 0), row stride
+};
+#define NFB_DW_WAVES 16
+#define NFB_DW_MAX_TILES NFB_DW_WAVES                    // one operand tile per wave and stage
+struct NfbDwJob {
+    int nseg, ntile;
+    NfbDwSeg seg[4];
+    NfbDwTile tile[NFB_DW_MAX_TILES];
+    NfbDwProd prod[NFB_DW_WAVES];
+};
+
+#define NFB_DW_JOBS 12
+#define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
+#define NFB_DW_NSET 3                                    // register sets of raw tiles: 2 stages of loads in flight
+#define NFB_DW_CVT_U4 (NFB_DW_MAX_TILES * 128)           // 16-byte units: per tile 64 lanes x (hi, lo)
+__constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
+
+static void nfb_build_dw_jobs(NfbDwJob* jobs) {
+    using namespace nfl;
+    int nj = 0;
+    int first_tile[4];
+    auto new_job = [&]() -> NfbDwJob& {
+        NfbDwJob& j = jobs[nj++];
+        j.nseg = j.ntile = 0;
+        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0};
+        for (auto& t : j.tile) t = NfbDwTile{0, 0, -1};
+        for (auto& p : j.prod) p = NfbDwProd{0, 0, 0, 0, 0, 0, 0, 0};   // idle wave: multiplies tiles 0, 1 and stores nothing
+        return j;
+    };
+    // segment + its tiles; cs >= 0: slab offset of the column sums of the section
+    auto add_seg = [&](NfbDwJob& j, int kind, int sec, int width, int cs) {
+        j.seg[j.nseg] = NfbDwSeg{kind, sec, width};
+        first_tile[j.nseg] = j.ntile;
+        for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
+        return j.nseg++;
+    };
+    // rows [a0, a0 + a_valid) of segment sa  x  columns [b0, b0 + b_valid) of segment sb   (a0, b0 multiples of 32)
+    auto prod = [&](int sa, int a0, int a_valid, int sb, int b0, int b_valid, int out_off, int ldo) {
+        return NfbDwProd{(a_valid + 31) / 32, (b_valid + 31) / 32, first_tile[sa] + a0 / 32, first_tile[sb] + b0 / 32,
+                         a_valid, b_valid, out_off, ldo};
+    };
+    // 256 x 256 layers: 4 x 4 blocks of 64 x 64
+    auto layer256 = [&](int zsec, int bsec, int gout, int cs) {
+        NfbDwJob& j = new_job();
+        const int sa = add_seg(j, 0, zsec, 256, cs), sb = add_seg(j, 2, bsec, 256, -1);
+        for (int w = 0; w < 16; ++w) {
+            const int ag = w >> 2, bg = w & 3;
+            j.prod[w] = prod(sa, 64 * ag, 64, sb, 64 * bg, 64, gout + 64 * ag * 256 + 64 * bg, 256);
+        }
+    };
+    layer256(Z_L1, S_H0, G_L1, CS_L0 + 256);
+    layer256(Z_L2, S_H1, G_L2, CS_L0 + 512);
+    layer256(Z_L3, S_H2, G_L3B, -1);
+    layer256(Z_L4, S_H3, G_L4, CS_L0 + 1024);
+    layer256(Z_L5, S_H4, G_L5, CS_L0 + 1280);
+    layer256(Z_FEAT, S_H5, G_FEAT, CS_L0 + 1536);
+    for (int q = 0; q < 2; ++q) {   // the two products against the positional encoding: dZ_L0 x PE, dZ_L3 x PE
+        NfbDwJob& j = new_job();
+        const int sz = add_seg(j, 0, q ? Z_L3 : Z_L0, 256, q ? CS_L0 + 768 : CS_L0), sp = add_seg(j, 2, S_PE, 64, -1);
+        for (int w = 0; w < 8; ++w) j.prod[w] = prod(sz, 32 * w, 32, sp, 0, 64, (q ? G_L3A : G_L0) + 32 * w * 64, 64);
+    }
+    {   // (dZ_D0 | d_raw) x feat
+        NfbDwJob& j = new_job();
+        const int sz = add_seg(j, 0, Z_D0, 128, CS_D0), sf = add_seg(j, 2, S_FEAT, 256, -1), sr = add_seg(j, 1, 0, 4, -1);
+        for (int w = 0; w < 8; ++w) {
+            const int ag = w >> 2, bg = w & 3;
+            j.prod[w] = prod(sz, 64 * ag, 64, sf, 64 * bg, 64, G_D0A + 64 * ag * 256 + 64 * bg, 256);
+        }
+        for (int bg = 0; bg < 4; ++bg)     // row 3 (d sigma) = fc_alpha.weight gradient
+            j.prod[8 + bg] = prod(sr, 0, 4, sf, 64 * bg, 64, G_ALPHA + 64 * bg, 256);
+    }
+    {   // dZ_D1 x d0 and dZ_D2 x d1
+        NfbDwJob& j = new_job();
+        const int z1 = add_seg(j, 0, Z_D1, 128, CS_D0 + 128), a0 = add_seg(j, 2, S_D0, 128, -1);
+        const int z2 = add_seg(j, 0, Z_D2, 128, CS_D0 + 256), a1 = add_seg(j, 2, S_D1, 128, -1);
+        for (int w = 0; w < 4; ++w) {
+            const int ag = w >> 1, bg = w & 1;
+            j.prod[w] = prod(z1, 64 * ag, 64, a0, 64 * bg, 64, G_D1 + 64 * ag * 128 + 64 * bg, 128);
+            j.prod[4 + w] = prod(z2, 64 * ag, 64, a1, 64 * bg, 64, G_D2 + 64 * ag * 128 + 64 * bg, 128);
+        }
+    }
+    {   // dZ_D0 x dir features, d_raw x d2 (fc_rgb.weight; the 4 output-bias gradients are the column sums of d_raw)
+        NfbDwJob& j = new_job();
+        const int sz = add_seg(j, 0, Z_D0, 128, -1), sd = add_seg(j, 2, S_DIRF, 16, -1), sr = add_seg(j, 1, 0, 4, CS_RGB);
+        const int s2 = add_seg(j, 2, S_D2, 128, -1);
+        for (int ag = 0; ag < 2; ++ag) j.prod[ag] = prod(sz, 64 * ag, 64, sd, 0, 16, G_D0B + 64 * ag * 16, 16);
+        for (int bg = 0; bg < 2; ++bg) j.prod[2 + bg] = prod(sr, 0, 4, s2, 64 * bg, 64, G_RGB + 64 * bg, 128);
+    }
+    // nj == NFB_DW_JOBS by construction
+}
+
+__device__ __forceinline__ void nfb_dw_split(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const __bf16 hh = (__bf16)x[j];
+        hi[j] = hh;
+        lo[j] = (__bf16)(x[j] - (float)hh);
+    }
+}
+
+// L step for one tile: lane (h, c) <- feature c of points p0 + 8 h .. + 7 (zero beyond the slice / the section width)
+// L step: raw buffer loads.  voff = this lane's byte offset of (point 8 h of the stage, its feature) within the slice's rows
+// of the section, or 0x80000000 for lanes past the section width; the 8 points are reached through the scalar offset
+// j * stride.  The hardware range check sees only voff (never the scalar offset), so the descriptor of the pipelined loop
+// covers exactly the WHOLE stages of the slice: they need no test, and stages past them (the pipeline overruns by a few)
+// read 0 through the check.  The partial stage the last slice can end with is handled after the loop (nfb_dw_load_tail).
+__device__ __forceinline__ void nfb_dw_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned stride_b, float (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(j * stride_b), 0));
+}
+__device__ __forceinline__ void nfb_dw_load_tail(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned stride_b, int n_ok, int h,
+                                                 float (&x)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(8 * h + j < n_ok ? voff : 0x80000000u),
+                                                                            (int)(j * stride_b), 0));
+}
+
+__global__ void __launch_bounds__(64 * NFB_DW_WAVES, 1)
+k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
+                     int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
+    using namespace nfl;
+    __shared__ __attribute__((aligned(16))) uint4 lds_cvt[2 * NFB_DW_CVT_U4];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int h = lane >> 5, c = lane & 31;
+    const NfbDwJob& job = c_dwb_jobs[blockIdx.x];
+    const NfbDwProd pr = job.prod[wave];
+    const int slice = blockIdx.y;
+    const int64_t p_begin = (int64_t)slice * pts_per_slice;
+    int64_t p_end = p_begin + pts_per_slice;
+    if (p_end > n_points) p_end = n_points;
+    const int n_stages = p_end > p_begin ? (int)((p_end - p_begin) / NFB_DW_PTS) : 0;                // whole stages
+    const int n_tail = p_end > p_begin ? (int)(p_end - p_begin) - n_stages * NFB_DW_PTS : 0;         // points of the partial one
+
+    // the tile this wave loads + converts every stage
+    const bool t_on = wave < job.ntile;
+    const NfbDwTile tl = job.tile[t_on ? wave : 0];
+    const NfbDwSeg tsg = job.seg[tl.seg];
+    const bool t_fok = tl.f0 + c < tsg.width;
+    const unsigned t_stride_b = 4u * (unsigned)tsg.width;
+    const float* t_g = (tsg.kind == 1 ? d_raw : (tsg.kind == 0 ? dz : saved) + (int64_t)tsg.sec * n_points) + p_begin * tsg.width;
+    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(t_g), (short)0, (int)(n_stages * NFB_DW_PTS * t_stride_b), 0x00020000);
+    const unsigned t_voff = (t_on && t_fok) ? 4u * (unsigned)(tl.f0 + c) + (unsigned)(8 * h) * t_stride_b : 0x80000000u;
+    float t_cs = 0.f;
+    float xs[NFB_DW_NSET][8];
+    auto load = [&](int i, float (&x)[8]) { nfb_dw_load(t_rsrc, t_voff + (unsigned)i * NFB_DW_PTS * t_stride_b, t_stride_b, x); };
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
+
+    // One stage: M(i-1) out of fragment buffer (i+1)&1, C(i) into buffer i&1, L(i+2).  Always the full 2 x 2 block of
+    // MFMAs (narrower products simply do not store the surplus tiles).  The three MFMA groups (hi.hi, hi.lo, lo.hi; four
+    // independent accumulators each) are interleaved with the vector work of C and the loads of L so that one hides
+    // under the other; sched_barrier keeps the compiler from re-clustering them.
+    auto stage = [&](int i, const float (&xc)[8], float (&xn)[8]) {
+        const uint4* rd = lds_cvt + ((i + 1) & 1) * NFB_DW_CVT_U4 + lane;
+        uint4* wr = lds_cvt + (i & 1) * NFB_DW_CVT_U4 + wave * 128 + lane;
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            ah[t] = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128]);
+            bh[t] = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + t) * 128]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            bf16x8 hi, lo;
+            nfb_dw_split(xc, hi, lo);
+            t_cs += ((xc[0] + xc[1]) + (xc[2] + xc[3])) + ((xc[4] + xc[5]) + (xc[6] + xc[7]));
+            wr[0] = __builtin_bit_cast(uint4, hi);
+            wr[64] = __builtin_bit_cast(uint4, lo);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) bl[t] = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + t) * 128 + 64]);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) al[t] = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
+        load(i + 2, xn);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
+        __syncthreads();
+    };
+
+    // the first M step (i = 0) reads fragment buffer 1 before anything was converted into it
+    for (int e = threadIdx.x; e < NFB_DW_CVT_U4; e += 64 * NFB_DW_WAVES) lds_cvt[NFB_DW_CVT_U4 + e] = make_uint4(0u, 0u, 0u, 0u);
+    load(0, xs[0]);
+    load(1, xs[1]);
+    __syncthreads();
+    for (int i0 = 0; i0 <= n_stages; i0 += NFB_DW_NSET) {
+#pragma unroll
+        for (int q = 0; q < NFB_DW_NSET; ++q) stage(i0 + q, xs[q], xs[(q + 2) % NFB_DW_NSET]);
+    }
+    if (n_tail > 0) {   // the partial stage (last slice only), not pipelined
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(t_g), (short)0, (int)((p_end - p_begin) * (int64_t)t_stride_b), 0x00020000);
+        float xt[8];
+        nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
+        bf16x8 hi, lo;
+        nfb_dw_split(xt, hi, lo);
+        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
+        lds_cvt[wave * 128 + lane] = __builtin_bit_cast(uint4, hi);
+        lds_cvt[wave * 128 + lane + 64] = __builtin_bit_cast(uint4, lo);
+        __syncthreads();
+        const uint4* rd = lds_cvt + lane;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 ah = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128]), al = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
+                const bf16x8 bh = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + u) * 128]), bl = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + u) * 128 + 64]);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t][u], 0, 0, 0);
+                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t][u], 0, 0, 0);
+            }
+    }
+
+    // D of tile (t, u): lane (h, c), reg r -> row 32 t + (r & 3) + 8 (r >> 2) + 4 h, column 32 u + c
+    float* slab = slabs + (int64_t)slice * SLAB_FLOATS;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= pr.a_valid) continue;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (32 * u + c < pr.b_valid) slab[pr.out_off + row * pr.ldo + 32 * u + c] = acc[t][u][r];
+        }
+    }
+    if (t_on && tl.cs_off >= 0) {
+        const float v = t_cs + __shfl_xor(t_cs, 32, 64);
+        if (h == 0 && t_fok) slab[tl.cs_off + c] = v;
+    }
+}
+
+static std::once_flag g_dwb_once[64];
+
+// called by nf_paper_mlp_bwd_bf16 (nf_mlp_bwd.hip); slabs: n_slices x SLAB_FLOATS
+int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                       int n_slices, float* slabs, nf_stream_t stream) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    int rc = 0;
+    std::call_once(g_dwb_once[dev], [&]() {
+        static NfbDwJob jobs[NFB_DW_JOBS];
+        nfb_build_dw_jobs(jobs);
+        hipError_t ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs), jobs, sizeof(jobs));
+        if (ee != hipSuccess) rc = (int)ee;
+    });
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_paper_dw_gemm_bf16, dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream), dz, d_raw, saved,
+                       n_points, pts_per_slice, slabs);
+    NF_RETURN_LAUNCH();
+}
+
+// slices for the split-bf16 dW kernel: 12 bundles x 42 slices = 504 workgroups = two rounds of the 256 CUs
+void nfb_dw_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
+    int64_t pps = (n_points + 41) / 42;
+    pps = (pps + 15) / 16 * 16;
+    if (pps < 256) pps = 256;
+    *pts_per_slice = pps;
+    *n_slices = (int)((n_points + pps - 1) / pps);
+}

@@ -436,9 +436,16 @@ static void nf_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices)
     *n_slices = (int)((n_points + pps - 1) / pps);
 }
 
+// defined in nf_mlp_bf16_dw.hip
+void nfb_dw_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices);
+int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                       int n_slices, float* slabs, nf_stream_t stream);
+
 extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
-    int64_t pps; int ns;
+    int64_t pps; int ns, ns_b;
     nf_bwd_plan(n_points, &pps, &ns);
+    nfb_dw_plan(n_points, &pps, &ns_b);
+    if (ns_b > ns) ns = ns_b;
     return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS;
 }
 
@@ -448,9 +455,9 @@ static std::once_flag g_jobs_once[64];
 int nfb_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
                          nf_stream_t stream);
 
-static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const float* cond, const float* saved,
-                       const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
-                       nf_stream_t stream) {
+static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, bool split_dw, const float* cond,
+                       const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
+                       size_t workspace_floats, float* grads, nf_stream_t stream) {
     using namespace nfl;
     if (!packed || (!packed_t && !packed_t_bf16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0)
         return NF_EINVAL;
@@ -469,7 +476,8 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     });
     if (rc) return rc;
     int64_t pps; int ns;
-    nf_bwd_plan(n_points, &pps, &ns);
+    if (split_dw) nfb_dw_plan(n_points, &pps, &ns);
+    else nf_bwd_plan(n_points, &pps, &ns);
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
@@ -487,7 +495,12 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
         hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
                            n_points, dz);
     }
-    hipLaunchKernelGGL(k_paper_dw_gemm, dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, dz, d_raw, saved, n_points, pps, slabs);
+    if (split_dw) {
+        const int rc3 = nfb_launch_dw_gemm(dz, d_raw, saved, n_points, pps, ns, slabs, stream);
+        if (rc3) return rc3;
+    } else {
+        hipLaunchKernelGGL(k_paper_dw_gemm, dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, dz, d_raw, saved, n_points, pps, slabs);
+    }
     hipLaunchKernelGGL(k_paper_grad_reduce, dim3(512), dim3(256), 0, s, slabs, ns, sum);
     NfGradOffsets offs;
     offs.off[0] = 0;
@@ -500,14 +513,15 @@ extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, cons
                                 const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
                                 float* grads, nf_stream_t stream) {
     if (!packed_t) return NF_EINVAL;
-    return nf_bwd_impl(packed, packed_t, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+    return nf_bwd_impl(packed, packed_t, nullptr, false, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
 }
 
-// Same, with the dX chain on the split-bf16 kernel (nf_mlp_bf16_bwd.hip).  `saved` must come from nf_paper_mlp_fwd_train_bf16
-// (it carries the ReLU bit masks); the weight-gradient GEMMs and the reduction are the exact-f32 ones.
+// Same, with the dX chain (nf_mlp_bf16_bwd.hip) and, unless exact_dw, the weight-gradient GEMMs (nf_mlp_bf16_dw.hip) on the
+// split-bf16 kernels.  `saved` must come from nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks the chain reads).
 extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
                                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
-                                     float* grads, nf_stream_t stream) {
+                                     float* grads, int exact_dw, nf_stream_t stream) {
     if (!packed_t_bf16) return NF_EINVAL;
-    return nf_bwd_impl(packed, nullptr, packed_t_bf16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+    return nf_bwd_impl(packed, nullptr, packed_t_bf16, exact_dw == 0, cond, saved, d_raw, n_rays, n_samples, workspace,
+                       workspace_floats, grads, stream);
 }

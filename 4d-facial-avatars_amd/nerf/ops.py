@@ -241,10 +241,10 @@ def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):
     return raw, (saved,)
 
 
-def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False):
+def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False, exact_dw=False):
     """d_raw (n_rays, n_samples, 4) -> ([26 parameter gradients in state_dict order], d_latent (32)).
     layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3).  split=True runs the dX chain on the
-    split-bf16 kernel (requires `saved` from the split-bf16 training forward); dW/db stay exact f32."""
+    split-bf16 kernel (requires `saved` from the split-bf16 training forward) and, unless exact_dw, the dW GEMMs too."""
     (saved_t,) = saved
     d_raw = _c(d_raw)
     dev = H.require_device(packed, cond, saved_t, d_raw)
@@ -257,7 +257,8 @@ def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False):
         if split:
             packed_bt = model.hip_weights().get_bf16_t()
             H.check(lib.nf_paper_mlp_bwd_bf16(H.ptr(packed), H.ptr(packed_bt), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
-                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd_bf16")
+                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), int(bool(exact_dw)), H.stream_ptr(dev)),
+                    "nf_paper_mlp_bwd_bf16")
         else:
             packed_t = model.hip_weights().get_t()
             H.check(lib.nf_paper_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,

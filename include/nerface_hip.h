@@ -108,13 +108,14 @@ int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* co
                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
                      size_t workspace_floats, float* grads, nf_stream_t stream);
 
-/* dX chain on the split-bf16 kernel (the weight-gradient GEMMs stay exact f32).  `saved` must have been written by
- * nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks this chain reads).                                      */
+/* Backward on the split-bf16 kernels: the dX chain and (unless exact_dw != 0) the weight-gradient GEMMs; bias/latent
+ * reductions stay f32.  `saved` must have been written by nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks
+ * the chain reads).                                                                                                  */
 size_t nf_paper_packed_bwd_bf16_bytes(void);
 int nf_paper_pack_bwd_bf16(const float* const* params, void* packed_t_bf16, nf_stream_t stream);
 int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
                           const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
-                          size_t workspace_floats, float* grads, nf_stream_t stream);
+                          size_t workspace_floats, float* grads, int exact_dw, nf_stream_t stream);
 
 /* ---- K5: volume integrator -- replaces volume_render_radiance_field (V:7-75) + cumprod_exclusive
  *      (H:44-65) + the background overwrite of T:95-96 ----------------------------------------------- */

@@ -134,6 +134,14 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s, split):
     e = rel_l2(g_lat.cpu(), lat.grad)
     print(f"mlp bwd ({n_rays}x{s}, split={split}): worst param rel L2 {worst:.2e}, latent {e:.2e}")
     assert e < (3e-4 if split else 1e-4)
+    if split:     # the split-bf16 dW GEMMs against the exact-f32 ones on the SAME saved activations and dZ
+        grads_x, g_lat_x = ops.paper_mlp_bwd(m, pk, cond, z.to(gpu), d_raw.to(gpu), saved, split=True, exact_dw=True)
+        for (k, _), gs, gx in zip(m.named_parameters(), grads, grads_x):
+            if gx is None:
+                assert gs is None
+                continue
+            assert rel_l2(gs.cpu(), gx.cpu()) < 1e-4, (k, rel_l2(gs.cpu(), gx.cpu()))
+        assert rel_l2(g_lat.cpu(), g_lat_x.cpu()) < 1e-4
 
 
 def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
