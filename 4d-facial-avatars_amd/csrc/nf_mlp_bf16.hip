@@ -144,7 +144,7 @@ extern "C" int nf_paper_mlp_fwd_bf16(const void* packed_bf16, const float* cond,
 }
 
 // Training forward on the split-bf16 kernel: also fills `saved` (nf_paper_saved_floats(n_points) floats, f32, the layout
-// nf_paper_mlp_bwd reads).  The backward stays on the exact-f32 kernels.
+// nf_paper_mlp_bwd reads) plus the ReLU bit masks nf_paper_mlp_bwd_bf16 reads (S_MASK).
 extern "C" int nf_paper_mlp_fwd_train_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
                                            const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                                            float* saved, nf_stream_t stream) {

@@ -197,10 +197,11 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
         print(json.dumps({
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32", "data": "synthetic",
             "config": {"workload": "configs[2]: paper-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
                                    "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
-                       "rays_per_step": n_rays * world, "parallelism": f"dp{world}"}}), flush=True)
+                       "rays_per_step": n_rays * world, "parallelism": f"dp{world}", "mlp_precision": args.precision}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
