@@ -14,6 +14,7 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_dw.h"
 
 struct NfParamPtrs26 { const float* p[NF_PAPER_NUM_PARAMS]; };
 
@@ -197,22 +198,9 @@ k_paper_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restric
 }
 
 // =================================================================================================
-// B2: weight-gradient GEMMs.   One WAVE = one job: a 128 x 128 tile of  dW = A^T B  over one point slice.
-//   A = dZ (or d_raw) [points][lda], B = saved activations [points][ldb].
-//   MFMA: D[n][k] += A[n][pt] * B[pt][k]; step r of a 16-point chunk takes from lane group g the point
-//   chunk + 4 r + g; lane (g, i) therefore issues dword loads of 16 consecutive floats per row (64 B).
+// B2: weight-gradient GEMMs (generic kernel in nf_mlp_dw.h); the paper model's job table
 // =================================================================================================
-struct NfDwJob {
-    int a_kind;      // 0: dz section, 1: d_raw
-    int a_sec;       // section offset (floats per point) within dz
-    int lda, a_col0, n_valid;
-    int b_sec, ldb, b_col0, k_valid;
-    int out_off, ldo;
-    int cs_off;      // >= 0: also write column sums of A (bias grads) for this n-block
-};
-
 #define NF_DW_JOBS 36
-__constant__ NfDwJob c_dw_jobs[NF_DW_JOBS];
 
 static void nf_build_dw_jobs(NfDwJob* j) {
     using namespace nfl;
@@ -247,111 +235,9 @@ static void nf_build_dw_jobs(NfDwJob* j) {
     // n == NF_DW_JOBS by construction
 }
 
-__global__ void __launch_bounds__(256, 1)
-k_paper_dw_gemm(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
-                int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
-    using namespace nfl;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, i = lane & 15;
-    const int jid = blockIdx.x * 4 + wave;
-    const int slice = blockIdx.y;
-    if (jid >= NF_DW_JOBS) return;
-    const NfDwJob job = c_dw_jobs[jid];
-    const int64_t p_begin = (int64_t)slice * pts_per_slice;
-    int64_t p_end = p_begin + pts_per_slice;
-    if (p_end > n_points) p_end = n_points;
-    const float* A = (job.a_kind ? d_raw : dz + (int64_t)job.a_sec * n_points) + job.a_col0;
-    const float* B = saved + (int64_t)job.b_sec * n_points + job.b_col0;
-    float* out = slabs + (int64_t)slice * SLAB_FLOATS + job.out_off;
-    const int lda = job.lda, ldb = job.ldb;
-
-    // Row/column order inside the 128 x 128 tile is free, so it is chosen for 16-byte operand loads: lane (g, i) reads
-    // 4 consecutive features 64 sb + 4 i .. +3 of ONE point; component t of that float4 is the lane's operand for MFMA tile
-    // (sb, t), whose 16 rows are therefore the features 64 sb + 4 i' + t.  One load feeds four tiles.
-    bool a_ok[2], b_ok[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { a_ok[q] = 64 * q + 4 * i < job.n_valid; b_ok[q] = 64 * q + 4 * i < job.k_valid; }
-
-    f32x4 acc[8][8];                        // [4 sb + t][4 sk + t']
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int kt = 0; kt < 8; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 cs[2];
-    cs[0] = cs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    f32x4 a[4][2], b[4][2], an[4][2], bn[4][2];     // [step r][sub-block]
-    auto load_chunk = [&](int64_t p, f32x4 (&aa)[4][2], f32x4 (&bb)[4][2]) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t row = p + 4 * r + g;
-            const bool rv = row < p_end;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                aa[r][q] = (rv && a_ok[q]) ? *reinterpret_cast<const f32x4*>(A + row * lda + 64 * q + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-                bb[r][q] = (rv && b_ok[q]) ? *reinterpret_cast<const f32x4*>(B + row * ldb + 64 * q + 4 * i) : (f32x4){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-    if (p_begin < p_end) load_chunk(p_begin, a, b);
-    for (int64_t p = p_begin; p < p_end; p += 16) {
-        const bool more = p + 16 < p_end;
-        if (more) load_chunk(p + 16, an, bn);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            cs[0] += a[r][0];
-            cs[1] += a[r][1];
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-                for (int kt = 0; kt < 8; ++kt)
-                    acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r][nt >> 2][nt & 3], b[r][kt >> 2][kt & 3], acc[nt][kt], 0, 0, 0);
-        }
-        if (more) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) { a[r][q] = an[r][q]; b[r][q] = bn[r][q]; }
-        }
-    }
-    // D of tile (nt = 4 sb + t, kt = 4 sk + t'): lane (g, c = i), reg r' -> row n = 64 sb + 4 (4 g + r') + t,
-    // column k = 64 sk + 4 c + t'.  For fixed (nt, r', sk) a lane holds 4 consecutive k: one 16-byte store.
-#pragma unroll
-    for (int nt = 0; nt < 8; ++nt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int nrow = 64 * (nt >> 2) + 4 * (4 * g + r) + (nt & 3);
-            if (nrow < job.n_valid) {
-#pragma unroll
-                for (int sk = 0; sk < 2; ++sk)
-                    if (b_ok[sk])
-                        *reinterpret_cast<f32x4*>(out + (int64_t)nrow * job.ldo + 64 * sk + 4 * i) =
-                            (f32x4){acc[nt][4 * sk + 0][r], acc[nt][4 * sk + 1][r], acc[nt][4 * sk + 2][r], acc[nt][4 * sk + 3][r]};
-            }
-        }
-    if (job.cs_off >= 0) {
-        float* cso = slabs + (int64_t)slice * SLAB_FLOATS + job.cs_off;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            f32x4 v = cs[q];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) { v[t] += __shfl_xor(v[t], 16, 64); v[t] += __shfl_xor(v[t], 32, 64); }
-            if (g == 0 && a_ok[q]) *reinterpret_cast<f32x4*>(cso + 64 * q + 4 * i) = v;
-        }
-    }
-}
-
 // =================================================================================================
 // B3: reduce over slices + scatter to the reference parameter layout
 // =================================================================================================
-__global__ void __launch_bounds__(256) k_paper_grad_reduce(const float* __restrict__ slabs, int n_slices, float* __restrict__ sum) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfl::SLAB_FLOATS; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < n_slices; ++k) s += slabs[(int64_t)k * nfl::SLAB_FLOATS + e];
-        sum[e] = s;
-    }
-}
-
 struct NfGradOffsets { int off[NF_PAPER_NUM_PARAMS + 1]; };
 
 __device__ __forceinline__ int nf_pe_col_to_slot(int col) { return nfl::pe_col_to_slot(col); }
@@ -428,14 +314,6 @@ static const int NF_PARAM_NUMEL[NF_PAPER_NUM_PARAMS] = {
 
 extern "C" size_t nf_paper_grad_floats(void) { return (size_t)nfl::GRAD_FLOATS; }
 
-static void nf_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
-    int64_t pps = (n_points + 27) / 28;
-    pps = (pps + 15) / 16 * 16;
-    if (pps < 1024) pps = 1024;
-    *pts_per_slice = pps;
-    *n_slices = (int)((n_points + pps - 1) / pps);
-}
-
 // defined in nf_mlp_bf16_dw.hip
 void nfb_dw_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices);
 int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
@@ -449,7 +327,7 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS;
 }
 
-static std::once_flag g_jobs_once[64];
+static NfDwJobTable g_paper_jobs;
 
 // defined in nf_mlp_bf16_bwd.hip
 int nfb_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
@@ -467,14 +345,9 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= 64) return NF_EINVAL;
-    int rc = 0;
-    std::call_once(g_jobs_once[dev], [&]() {
-        NfDwJob jobs[NF_DW_JOBS];
-        nf_build_dw_jobs(jobs);
-        hipError_t ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dw_jobs), jobs, sizeof(jobs));
-        if (ee != hipSuccess) rc = (int)ee;
-    });
-    if (rc) return rc;
+    const NfDwJob* jobs = nullptr;
+    const int rcj = g_paper_jobs.get(NF_DW_JOBS, nf_build_dw_jobs, &jobs);
+    if (rcj) return rcj;
     int64_t pps; int ns;
     if (split_dw) nfb_dw_plan(n_points, &pps, &ns);
     else nf_bwd_plan(n_points, &pps, &ns);
@@ -499,9 +372,10 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
         const int rc3 = nfb_launch_dw_gemm(dz, d_raw, saved, n_points, pps, ns, slabs, stream);
         if (rc3) return rc3;
     } else {
-        hipLaunchKernelGGL(k_paper_dw_gemm, dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, dz, d_raw, saved, n_points, pps, slabs);
+        hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
+                           saved, n_points, pps, slabs);
     }
-    hipLaunchKernelGGL(k_paper_grad_reduce, dim3(512), dim3(256), 0, s, slabs, ns, sum);
+    hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
     NfGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];

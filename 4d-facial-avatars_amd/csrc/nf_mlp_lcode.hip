@@ -7,26 +7,8 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_lcode_layout.h"
 
-namespace nlc {
-constexpr int FRAG = 256;
-constexpr int OFF_L1 = 0;                              // 4 PE chunks x 16 tiles
-constexpr int OFF_X0 = OFF_L1 + 4 * 16 * FRAG;         // 16 x 16 each
-constexpr int OFF_X1 = OFF_X0 + 16 * 16 * FRAG;
-constexpr int OFF_X2 = OFF_X1 + 16 * 16 * FRAG;
-constexpr int OFF_ALPHA = OFF_X2 + 16 * 16 * FRAG;     // 16 chunks x 1 tile (row 0)
-constexpr int OFF_FEAT = OFF_ALPHA + 16 * 1 * FRAG;
-constexpr int OFF_DIR = OFF_FEAT + 16 * 16 * FRAG;     // 16 feat chunks + 1 dir chunk, 8 tiles
-constexpr int OFF_RGB = OFF_DIR + 17 * 8 * FRAG;       // 8 chunks x 1 tile (rows 0..2)
-constexpr int OFF_WC1 = OFF_RGB + 8 * 1 * FRAG;        // [256][108] layer1.weight[:, 63:171]
-constexpr int OFF_WCD = OFF_WC1 + 256 * 108;           // [128][16]  layers_dir.0.weight[:, 256+6f+3sc+{1,2}]
-constexpr int OFF_BIAS = OFF_WCD + 128 * 16;
-constexpr int B_L1 = 0, B_X0 = 256, B_X1 = 512, B_X2 = 768, B_FEAT = 1024, B_ALPHA = 1280, B_DIR = 1296, B_RGB = 1424;
-constexpr int BIAS_FLOATS = 1440;
-constexpr int B_CVEC = BIAS_FLOATS, B_DVEC = B_CVEC + 108, COND_FLOATS = B_DVEC + 16;
-constexpr int PACKED = OFF_BIAS + BIAS_FLOATS;
-constexpr int NPARAMS = 16;   // layer1, layers_xyz.0..2, layers_dir.0, fc_alpha, fc_rgb, fc_feat (weight, bias each)
-}  // namespace nlc
 
 struct NfLcodePtrs { const float* p[nlc::NPARAMS]; };
 
@@ -151,11 +133,12 @@ extern "C" int nf_lcode_condition(const float* packed, const float* expr76, cons
     NF_RETURN_LAUNCH();
 }
 
-template <int NT>
+// SAVE = training forward: every layer output is also written to `saved` (layout nlc::S_*).
+template <int NT, bool SAVE>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z, int64_t n_points, int S,
-                float* __restrict__ raw) {
+                float* __restrict__ raw, float* __restrict__ saved) {
     using namespace nlc;
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -179,20 +162,31 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+        if (SAVE && p0 + 16 * t + c < n_points) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(saved + S_PE * n_points + p * 64 + 16 * j + 4 * g) = pe[t][j];
+            *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
+        }
     }
     f32x4 acc[NT][16];
+#define NF_LC_FINISH(NO_, RELU_, SEC_, WIDTH_)                                                        \
+    do {                                                                                              \
+        if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                     \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                \
+        if (SAVE) nf_store_global<NT, NO_>(acc, saved + (int64_t)(SEC_) * n_points, WIDTH_, p0, n_points, lane); \
+    } while (0)
     nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
     nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
-    nf_store_act<NT, 16, false>(acc, act4, lane);
+    NF_LC_FINISH(16, false, S_L1, 256);
     nf_init_acc<NT, 16>(acc, cond + B_X0, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_X0 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_LC_FINISH(16, true, S_X0, 256);
     nf_init_acc<NT, 16>(acc, cond + B_X1, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_X1 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_LC_FINISH(16, true, S_X1, 256);
     nf_init_acc<NT, 16>(acc, cond + B_X2, lane);
     nf_mma_from_lds<NT, 16>(acc, W + OFF_X2 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_LC_FINISH(16, true, S_X2, 256);
     nf_init_acc<NT, 1>(acc, cond + B_ALPHA, lane);                       // fc_alpha(x)
     nf_mma_from_lds<NT, 1>(acc, W + OFF_ALPHA / 4, 16, act4, lane);
     float sigma_raw[NT];
@@ -200,11 +194,12 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
     nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);                       // feat = relu(fc_feat(x))
     nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
+    NF_LC_FINISH(16, true, S_FEAT, 256);
     nf_init_acc<NT, 8>(acc, cond + B_DIR, lane);                         // relu(layers_dir.0([feat | dir]))
     nf_mma_from_lds<NT, 8>(acc, W + OFF_DIR / 4, 16, act4, lane);
     nf_mma_from_regs<NT, 8, 1>(acc, W + OFF_DIR / 4 + 16 * 8 * 64, dirf, lane);
-    nf_store_act<NT, 8, true>(acc, act4, lane);
+    NF_LC_FINISH(8, true, S_DIR, 128);
+#undef NF_LC_FINISH
     nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
     nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
     if (g == 0) {
@@ -216,8 +211,8 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
 }
 
-extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
-                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+static int nf_lcode_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                               const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (!packed || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;
@@ -225,7 +220,25 @@ extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const fl
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    hipLaunchKernelGGL((k_lcode_mlp_fwd<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro, rd,
-                       rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+    if (saved)
+        hipLaunchKernelGGL((k_lcode_mlp_fwd<NT, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
+                           rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
+    else
+        hipLaunchKernelGGL((k_lcode_mlp_fwd<NT, false>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
+                           rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, (float*)nullptr);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    return nf_lcode_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, nullptr, stream);
+}
+
+extern "C" size_t nf_lcode_saved_floats(int64_t n_points) { return (size_t)nlc::SAVED_PER_POINT * (size_t)n_points; }
+
+// Training forward: also fills `saved` (nf_lcode_saved_floats(n_points) floats), which nf_lcode_mlp_bwd reads.
+extern "C" int nf_lcode_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                      const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
+    if (!saved) return NF_EINVAL;
+    return nf_lcode_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, saved, stream);
 }

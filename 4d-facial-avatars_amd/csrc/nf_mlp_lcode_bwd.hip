@@ -1,0 +1,294 @@
+// Backward of the second model family (ConditionalBlendshapeLearnableCodeNeRFModel, reference nerf/models.py:529-636;
+// autograd through M:590-636 as the trainer drives it, TR:355-392): gradients w.r.t. its 16 parameter tensors and the
+// latent code, exact f32, same three stages as the paper model (nf_mlp_bwd.hip):
+//   B1 k_lcode_mlp_bwd_chain   dZ_dir -> dZ_feat -> dZ_x2 (+ d sigma * fc_alpha.weight: fc_alpha reads x) -> dZ_x1 -> dZ_x0
+//                              -> dZ_layer1 (layer1 has no activation), masks from the saved post-ReLU activations
+//   B2 k_dw_gemm<1>            dW = dZ^T . X over point slices (24 wave jobs), bias grads as column sums
+//   B3 k_grad_reduce<1>, k_lcode_grad_unpack   slabs -> the 16 reference-layout tensors (PE slot order -> columns, folded
+//                              expression / latent / (near, far) columns as outer products) + d latent = W1[:,139:171]^T db1
+#include <vector>
+#include <mutex>
+#include "nf_mlp_dev.h"
+#include "nf_mlp_lcode_layout.h"
+#include "nf_mlp_dw.h"
+
+struct NfLcodePtrsB { const float* p[nlc::NPARAMS]; };
+
+// =================================================================================================
+// transposed pack: block (ni, no), lane (g, i), r -> W[row = 16 ni + 4 g + r][col = 16 no + i]
+// =================================================================================================
+static void nf_lcode_table_t(std::vector<uint32_t>& t) {
+    using namespace nlc;
+    const uint32_t Z = 0xFF000000u;
+    t.assign(PACKED_T, Z);
+    auto fill = [&](int off, int nk, int no_tiles, int tensor, int n_rows, int n_cols) {
+        for (int ni = 0; ni < nk; ++ni)
+            for (int no = 0; no < no_tiles; ++no)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int r = 0; r < 4; ++r) {
+                        const int g = lane >> 4, i = lane & 15, row = 16 * ni + 4 * g + r, col = 16 * no + i;
+                        if (row < n_rows) t[(size_t)off + ((size_t)(ni * no_tiles + no) * 64 + lane) * 4 + r] = ((uint32_t)tensor << 24) | (uint32_t)(row * n_cols + col);
+                    }
+    };
+    fill(OFFT_RGB, 1, 8, 12, 3, 128);                       // fc_rgb.weight (3, 128)
+    fill(OFFT_DIR, 8, 16, 8, 128, 280);                     // layers_dir.0.weight[:, :256]
+    fill(OFFT_FEAT, 16, 16, 14, 256, 256);                  // fc_feat.weight
+    fill(OFFT_FEAT + 16 * 16 * FRAG, 1, 16, 10, 1, 256);    // chunk 16, slot 0: fc_alpha.weight (1, 256)
+    fill(OFFT_X2, 16, 16, 6, 256, 256);
+    fill(OFFT_X1, 16, 16, 4, 256, 256);
+    fill(OFFT_X0, 16, 16, 2, 256, 256);
+}
+
+__global__ void __launch_bounds__(256) k_lcode_pack_t(NfLcodePtrsB ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t code = table[i], id = code >> 24;
+        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+    }
+}
+
+static std::mutex g_lcode_t_mutex;
+static uint32_t* g_lcode_t_table[64] = {nullptr};
+
+extern "C" size_t nf_lcode_packed_bwd_floats(void) { return (size_t)nlc::PACKED_T; }
+
+extern "C" int nf_lcode_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream) {
+    if (!params || !packed_t) return NF_EINVAL;
+    NfLcodePtrsB ptrs;
+    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lock(g_lcode_t_mutex);
+        if (!g_lcode_t_table[dev]) {
+            std::vector<uint32_t> host;
+            nf_lcode_table_t(host);
+            uint32_t* d = nullptr;
+            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
+            g_lcode_t_table[dev] = d;
+        }
+    }
+    hipLaunchKernelGGL(k_lcode_pack_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_t_table[dev], packed_t, (int)nlc::PACKED_T);
+    NF_RETURN_LAUNCH();
+}
+
+// =================================================================================================
+// B1: backward chain
+// =================================================================================================
+template <int NT, int NO>
+__device__ __forceinline__ void nf_lc_zero_acc(f32x4 (&acc)[NT][16]) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][no] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// acc *= [X > 0] with X read from the saved activations ([n_points][width] row-major)
+template <int NT, int NO>
+__device__ __forceinline__ void nf_lc_mask(f32x4 (&acc)[NT][16], const float* __restrict__ sec, int width, int64_t p0, int64_t n_points,
+                                           int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(sec + p * width + 16 * no + 4 * g);
+            f32x4 v = acc[t][no];
+            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+            acc[t][no] = v;
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
+                      int64_t n_points, float* __restrict__ dz) {
+    using namespace nlc;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
+    const int64_t n = n_points;
+
+    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int64_t p = p0 + 16 * t + c;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
+        frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
+        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[NT][16];
+#define NF_LC_BWD_FINISH(NO_, MASKSEC_, MASKW_, ZSEC_)                                                  \
+    do {                                                                                                \
+        if ((MASKSEC_) >= 0) nf_lc_mask<NT, NO_>(acc, saved + (int64_t)(MASKSEC_) * n, MASKW_, p0, n, lane); \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
+        nf_store_global<NT, NO_>(acc, dz + (int64_t)(ZSEC_) * n, (NO_) * 16, p0, n, lane);              \
+    } while (0)
+    // d(layers_dir.0 out) = d rgb . fc_rgb.weight, masked by its ReLU
+    nf_lc_zero_acc<NT, 8>(acc);
+    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
+    NF_LC_BWD_FINISH(8, S_DIR, 128, Z_DIR);
+    // d feat = dZ_dir . layers_dir.0.weight[:, :256], masked by relu(fc_feat)
+    nf_lc_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_DIR / 4, 8, act4, lane);
+    NF_LC_BWD_FINISH(16, S_FEAT, 256, Z_FEAT);
+    // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight, masked by layers_xyz.2's ReLU
+    nf_lc_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_FEAT / 4, 16, act4, lane);
+    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_FEAT / 4 + 16 * 16 * 64, frag_sig, lane);
+    NF_LC_BWD_FINISH(16, S_X2, 256, Z_X2);
+    nf_lc_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X2 / 4, 16, act4, lane);
+    NF_LC_BWD_FINISH(16, S_X1, 256, Z_X1);
+    nf_lc_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X1 / 4, 16, act4, lane);
+    NF_LC_BWD_FINISH(16, S_X0, 256, Z_X0);
+    // d(layer1 out): layer1 has no activation (M:609)
+    nf_lc_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X0 / 4, 16, act4, lane);
+    NF_LC_BWD_FINISH(16, -1, 256, Z_L1);
+#undef NF_LC_BWD_FINISH
+}
+
+// =================================================================================================
+// B2 job table
+// =================================================================================================
+#define NF_LC_DW_JOBS 24
+static void nf_lcode_build_dw_jobs(NfDwJob* j) {
+    using namespace nlc;
+    int n = 0;
+    auto add = [&](int a_kind, int a_sec, int lda, int a_col0, int n_valid, int b_sec, int ldb, int b_col0, int k_valid, int out_off,
+                   int ldo, int cs_off) { j[n++] = NfDwJob{a_kind, a_sec, lda, a_col0, n_valid, b_sec, ldb, b_col0, k_valid, out_off, ldo, cs_off}; };
+    auto layer256 = [&](int zsec, int bsec, int ldb, int kdim, int gout, int cs) {
+        for (int nb = 0; nb < 2; ++nb)
+            for (int kb = 0; kb * 128 < kdim; ++kb)
+                add(0, zsec, 256, 128 * nb, 128, bsec, ldb, 128 * kb, kdim - 128 * kb < 128 ? kdim - 128 * kb : 128,
+                    gout + 128 * nb * kdim + 128 * kb, kdim, kb == 0 ? cs + 128 * nb : -1);
+    };
+    layer256(Z_L1, S_PE, 64, 64, G_L1, CS_L1);
+    layer256(Z_X0, S_L1, 256, 256, G_X0, CS_L1 + 256);
+    layer256(Z_X1, S_X0, 256, 256, G_X1, CS_L1 + 512);
+    layer256(Z_X2, S_X1, 256, 256, G_X2, CS_L1 + 768);
+    layer256(Z_FEAT, S_X2, 256, 256, G_FEAT, CS_L1 + 1024);
+    add(0, Z_DIR, 128, 0, 128, S_FEAT, 256, 0, 128, G_DIRA, 256, CS_DIR);
+    add(0, Z_DIR, 128, 0, 128, S_FEAT, 256, 128, 128, G_DIRA + 128, 256, -1);
+    add(0, Z_DIR, 128, 0, 128, S_DIRF, 16, 0, 16, G_DIRB, 16, -1);
+    add(1, 0, 4, 0, 4, S_DIR, 128, 0, 128, G_RGB, 128, CS_RGB);            // rows 0..2: fc_rgb.weight; cs[3] = d b_alpha
+    add(1, 0, 4, 0, 4, S_X2, 256, 0, 128, G_ALPHA, 256, -1);               // row 3 (d sigma): fc_alpha.weight (fc_alpha reads x)
+    add(1, 0, 4, 0, 4, S_X2, 256, 128, 128, G_ALPHA + 128, 256, -1);
+    // n == NF_LC_DW_JOBS by construction
+}
+
+// =================================================================================================
+// B3, second half: scatter to the reference parameter layout (order = nerf.models.LCODE_KEYS)
+// =================================================================================================
+struct NfLcodeGradOffsets { int off[nlc::NPARAMS + 1]; };
+
+__global__ void __launch_bounds__(256) k_lcode_grad_unpack(const float* __restrict__ sum, const float* __restrict__ packed,
+                                                           const float* __restrict__ cond, NfLcodeGradOffsets offs,
+                                                           float* __restrict__ grads) {
+    using namespace nlc;
+    const float* cvec = cond + B_CVEC;
+    const float* dvec = cond + B_DVEC;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < GRAD_FLOATS; e += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (e >= GRAD_PARAM_FLOATS) {                                // d latent_j = sum_n layer1.weight[n][139 + j] * d b1[n]
+            const int j = e - GRAD_PARAM_FLOATS;
+            const float* w1 = packed + OFF_WC1 + 76 + j;
+            for (int n = 0; n < 256; ++n) v += w1[n * 108] * sum[CS_L1 + n];
+            grads[e] = v;
+            continue;
+        }
+        int t = 0;
+        while (e >= offs.off[t + 1]) ++t;
+        const int local = e - offs.off[t];
+        switch (t) {
+            case 0: {  // layer1.weight [256][171] = [pe 63 | expr/3 76 | latent 32]
+                const int n = local / 171, col = local - 171 * n;
+                v = col < 63 ? sum[G_L1 + n * 64 + nfl::pe_col_to_slot(col)] : sum[CS_L1 + n] * cvec[col - 63];
+            } break;
+            case 1: v = sum[CS_L1 + local]; break;
+            case 2: v = sum[G_X0 + local]; break;
+            case 3: v = sum[CS_L1 + 256 + local]; break;
+            case 4: v = sum[G_X1 + local]; break;
+            case 5: v = sum[CS_L1 + 512 + local]; break;
+            case 6: v = sum[G_X2 + local]; break;
+            case 7: v = sum[CS_L1 + 768 + local]; break;
+            case 8: {  // layers_dir.0.weight [128][280] = [feat 256 | PE4(rd_z, near, far) 24]
+                const int n = local / 280, col = local - 280 * n;
+                if (col < 256) v = sum[G_DIRA + n * 256 + col];
+                else {
+                    const int q = col - 256, f = q / 6, rem = q - 6 * f, sc = rem / 3, comp = rem - 3 * sc;
+                    v = comp == 0 ? sum[G_DIRB + n * 16 + 4 * f + sc] : sum[CS_DIR + n] * dvec[4 * f + 2 * sc + (comp - 1)];
+                }
+            } break;
+            case 9: v = sum[CS_DIR + local]; break;
+            case 10: v = sum[G_ALPHA + 3 * 256 + local]; break;   // fc_alpha.weight [1][256] = row 3 (d sigma) of d_raw^T x
+            case 11: v = sum[CS_RGB + 3]; break;
+            case 12: v = sum[G_RGB + local]; break;               // fc_rgb.weight [3][128]
+            case 13: v = sum[CS_RGB + local]; break;
+            case 14: v = sum[G_FEAT + local]; break;
+            case 15: v = sum[CS_L1 + 1024 + local]; break;
+        }
+        grads[e] = v;
+    }
+}
+
+static const int NF_LC_PARAM_NUMEL[nlc::NPARAMS] = {256 * 171, 256, 65536, 256, 65536, 256, 65536, 256,   // layer1, layers_xyz.0..2
+                                                     128 * 280, 128, 256, 1, 384, 3, 65536, 256};          // layers_dir.0, fc_alpha, fc_rgb, fc_feat
+
+extern "C" size_t nf_lcode_grad_floats(void) { return (size_t)nlc::GRAD_FLOATS; }
+
+extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
+    int64_t pps; int ns;
+    nf_bwd_plan(n_points, &pps, &ns);
+    return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS;
+}
+
+static NfDwJobTable g_lcode_jobs;
+
+// grads: nf_lcode_grad_floats() floats = the 16 tensors in nerf.models.LCODE_KEYS order, flattened, then d latent (32)
+extern "C" int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved, const float* d_raw,
+                                int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
+                                nf_stream_t stream) {
+    using namespace nlc;
+    if (!packed || !packed_t || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0) return NF_EINVAL;
+    const int64_t n_points = n_rays * n_samples;
+    if (workspace_floats < nf_lcode_bwd_workspace_floats(n_points)) return NF_EINVAL;
+    const NfDwJob* jobs = nullptr;
+    const int rcj = g_lcode_jobs.get(NF_LC_DW_JOBS, nf_lcode_build_dw_jobs, &jobs);
+    if (rcj) return rcj;
+    int64_t pps; int ns;
+    nf_bwd_plan(n_points, &pps, &ns);
+    float* dz = workspace;
+    float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
+    float* sum = slabs + (size_t)ns * SLAB_FLOATS;
+    hipStream_t s = nf_s(stream);
+    constexpr int NT = NF_MLP_NT;
+    const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
+    const int64_t grid = (n_points + per_block - 1) / per_block;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_lcode_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);
+    hipLaunchKernelGGL((k_dw_gemm<1>), dim3((NF_LC_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_LC_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
+                       saved, n_points, pps, slabs);
+    hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
+    NfLcodeGradOffsets offs;
+    offs.off[0] = 0;
+    for (int i = 0; i < NPARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_LC_PARAM_NUMEL[i];
+    hipLaunchKernelGGL(k_lcode_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
+    NF_RETURN_LAUNCH();
+}

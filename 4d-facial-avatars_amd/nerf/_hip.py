@@ -52,6 +52,13 @@ _PROTOTYPES = {
     "nf_lcode_pack": (C.c_int, [_P, _P, _P]),
     "nf_lcode_condition": (C.c_int, [_P, _P, _P, _F, _F, _P, _P]),
     "nf_lcode_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_lcode_saved_floats": (_Z, [_L]),
+    "nf_lcode_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "nf_lcode_packed_bwd_floats": (_Z, []),
+    "nf_lcode_pack_bwd": (C.c_int, [_P, _P, _P]),
+    "nf_lcode_grad_floats": (_Z, []),
+    "nf_lcode_bwd_workspace_floats": (_Z, [_L]),
+    "nf_lcode_mlp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_eval_postprocess": (C.c_int, [_P, _P, _P, _I, _I, _F, _F, _F, _F, _P, _P, _P]),
     "nf_tiny_packed_floats": (_Z, []),
     "nf_tiny_pack": (C.c_int, [_P, _P, _P]),

@@ -120,9 +120,8 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
     r"""Second NeRFace model family (reference nerf/models.py:529-636; 6 config entries): layer1 without activation, three
     256-wide ReLU layers, feat = relu(fc_feat(x)), sigma = fc_alpha(x), one 280 -> 128 direction layer, fc_rgb.
     Same constructor signature, parameter names and shapes as the reference, so its checkpoints load.  The MI355X build
-    provides the inference forward (exact-f32 fused kernel) for the geometry the configs use: num_layers=4,
-    hidden_size=256 (the trainer never passes skip_connect_every, TR:100-109), 10/4 encoding functions; training this
-    family is not provided."""
+    provides the forward and the backward (exact-f32 fused kernels) for the geometry the configs use: num_layers=4,
+    hidden_size=256 (the trainer never passes skip_connect_every, TR:100-109), 10/4 encoding functions."""
 
     def __init__(self, num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4,
                  include_input_xyz=True, include_input_dir=True, use_viewdirs=True, include_expression=True, latent_code_dim=32):
@@ -156,6 +155,8 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         self.sigmoid = torch.sigmoid
         self._packed = None
         self._sig = None
+        self._packed_t = None
+        self._sig_t = None
 
     def fused_supported(self) -> bool:
         return (self.use_viewdirs and self.dim_xyz == 63 and self.dim_dir == 24 and self.dim_expression == 76
@@ -181,12 +182,24 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             self._sig = sig
         return self._packed
 
+    def _hip_packed_t(self):
+        import ctypes as C
+        from . import _hip as H
+        ps = self.hip_param_list()
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        if self._packed_t is None or sig != self._sig_t:
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            self._packed_t = torch.empty(lib.nf_lcode_packed_bwd_floats(), dtype=torch.float32, device=dev)
+            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_lcode_pack_bwd(arr, H.ptr(self._packed_t), H.stream_ptr(dev)), "nf_lcode_pack_bwd")
+            self._sig_t = sig
+        return self._packed_t
+
     def hip_forward(self, ro, rd, z, rd_view, expr, latent, near, far, need_grad):
         import numpy as np
         from . import _hip as H
-        if need_grad:
-            raise NotImplementedError("training ConditionalBlendshapeLearnableCodeNeRFModel is not provided by the MI355X build "
-                                      "(inference only); wrap the call in torch.no_grad()")
         packed = self._hip_packed()
         lib = H.lib()
         dev = H.require_device(packed, ro, rd, z, rd_view, expr, latent)
@@ -196,12 +209,36 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         with torch.cuda.device(dev):
             H.check(lib.nf_lcode_condition(H.ptr(packed), H.ptr(expr), H.ptr(latent), float(np.float32(near)), float(np.float32(far)),
                                            H.ptr(cond), H.stream_ptr(dev)), "nf_lcode_condition")
-            H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
-                                         n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
-        return raw, None
+            if not need_grad:
+                H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                             n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
+                return raw, None
+            saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
+            H.check(lib.nf_lcode_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                               n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_train")
+        return raw, (packed, cond, saved)
 
     def hip_backward(self, state, z, d_raw):
-        raise NotImplementedError("training ConditionalBlendshapeLearnableCodeNeRFModel is not provided by the MI355X build")
+        """d_raw (n_rays, n_samples, 4) -> ([16 parameter gradients in hip_param_list order], d latent (32))."""
+        from . import _hip as H
+        packed, cond, saved = state
+        lib = H.lib()
+        d_raw = d_raw.contiguous()
+        dev = H.require_device(packed, cond, saved, d_raw)
+        n_rays, n_samples = z.shape
+        packed_t = self._hip_packed_t()
+        ws_floats = lib.nf_lcode_bwd_workspace_floats(n_rays * n_samples)
+        ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
+        flat = torch.empty(lib.nf_lcode_grad_floats(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_lcode_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved), H.ptr(d_raw), n_rays, n_samples,
+                                         H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_lcode_mlp_bwd")
+        grads, off = [], 0
+        for p in self.hip_param_list():
+            n = p.numel()
+            grads.append(flat[off:off + n].view(p.shape))
+            off += n
+        return grads, flat[off:off + 32]
 
     def forward(self, x, expr=None, latent_code=None, **kwargs):
         raise NotImplementedError("evaluate this model through nerf.run_one_iter_of_nerf(...) (fused HIP kernel)")

@@ -139,6 +139,20 @@ int nf_lcode_condition(const float* packed, const float* expr76, const float* la
                        float* cond, nf_stream_t stream);
 int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                      const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+/* Training of the same family, exact f32 (autograd through M:590-636 as the trainer drives it, TR:355-392):
+ * forward that also fills `saved` (nf_lcode_saved_floats(n_rays*n_samples) floats), transposed weight image, and the
+ * backward: grads = the 16 tensors in the order of nerf.models.LCODE_KEYS (layer1, layers_xyz.0..2, layers_dir.0,
+ * fc_alpha, fc_rgb, fc_feat; weight then bias), flattened, followed by d latent (32).                                */
+size_t nf_lcode_saved_floats(int64_t n_points);
+int nf_lcode_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                           const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
+size_t nf_lcode_packed_bwd_floats(void);
+int nf_lcode_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream);
+size_t nf_lcode_grad_floats(void);
+size_t nf_lcode_bwd_workspace_floats(int64_t n_points);
+int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved, const float* d_raw,
+                     int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
+                     nf_stream_t stream);
 
 /* ---- BASELINE config 1: tiny_nerf.py (reference tiny_nerf.py:12-181) ----------------------------------------------
  * nf_tiny_mlp_fwd = compute_query_points_from_rays' pts = ro + rd*depth (tiny_nerf.py:59-63) + positional_encoding(., 10)

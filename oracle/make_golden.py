@@ -68,10 +68,49 @@ def run_reference(ref, c, grad=False):
     return out, grads
 
 
+def lcode_ref_model(ref, params):
+    m = ref.models.ConditionalBlendshapeLearnableCodeNeRFModel(
+        num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True,
+        num_layers=4, hidden_size=256, include_expression=True)
+    assert list(m.state_dict().keys()) == O.LCODE_KEYS
+    m.load_state_dict(params)
+    return m
+
+
+def make_lcode_grads(ref):
+    """Training step of the second model family through the reference (autograd, Q9 shim): loss, latent gradient and
+    per-tensor gradient norms / heads, same blob format as train_rand_64_64_grads.npz."""
+    c = C.build_case("train_rand_64_64")
+    pc, pf = O.init_lcode_params(5), O.init_lcode_params(6)
+    mc, mf = lcode_ref_model(ref, pc), lcode_ref_model(ref, pf)
+    opt = ref_options(ref, c["n_coarse"], c["n_fine"], True, c["noise_std"])
+    enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    latent = c["latent"].clone().requires_grad_(True)
+    with torch.enable_grad(), RI.injected_random([c["t_rand"], c["u"]], [c["noise_c_unit"], c["noise_f_unit"]]), RI.relu_clone_shim(ref):
+        out = ref.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"], c["rd"], opt, mode="train", encode_position_fn=enc_xyz,
+                                       encode_direction_fn=enc_dir, expressions=c["expr"], background_prior=c["bg"],
+                                       latent_code=latent)
+        loss = O.train_loss(out[0], out[3], c["tgt"], latent)
+        loss.backward()
+    blob = {"loss": loss.detach().numpy(), "latent": latent.grad.numpy(), "rgb_c": out[0].detach().numpy(), "rgb_f": out[3].detach().numpy()}
+    for tag, m in (("coarse", mc), ("fine", mf)):
+        for k, v in m.named_parameters():
+            g = v.grad
+            assert g is not None, k
+            blob[f"norm:{tag}.{k}"] = np.float64(g.double().norm())
+            blob[f"head:{tag}.{k}"] = g.reshape(-1)[:257].numpy()
+    np.savez_compressed(os.path.join(OUT, "lcode_train_rand_64_64_grads.npz"), **blob)
+    print("lcode grad fixture: loss", float(loss), "latent |g|", float(latent.grad.norm()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = RI.import_reference()
     torch.set_num_threads(8)
+    if len(sys.argv) > 1 and sys.argv[1] == "lcode_grads":        # regenerate only this fixture
+        make_lcode_grads(ref)
+        return
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     for name in C.CASES:
         c = C.build_case(name)
@@ -131,6 +170,7 @@ def main():
     out_or = O.render_rays(pc, pf, c["ro"], c["rd"], c["expr"], c["latent"], c["bg"], O.NEAR, O.FAR, 64, 128, mlp=O.lcode_mlp)
     print("lcode exact:", all(torch.equal(a, b) for a, b in zip(out_ref, out_or)), "w_last range", float(out_ref[6].min()), float(out_ref[6].max()))
     np.savez_compressed(os.path.join(OUT, "lcode_eval_det_64_128.npz"), **{n: a.numpy() for n, a in zip(names7, out_ref)})
+    make_lcode_grads(ref)
 
     # gradient fixture (reference autograd with the Q9 shim)
     c = C.build_case("train_rand_64_64")

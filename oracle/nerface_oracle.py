@@ -174,19 +174,33 @@ def init_lcode_params(seed: int, dtype=torch.float32, boost: bool = True) -> Dic
     return out
 
 
-def lcode_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor) -> torch.Tensor:
+def lcode_mlp(p: Dict[str, torch.Tensor], x87: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor, masks=None,
+              acts=None) -> torch.Tensor:
     """M:590-636: x = layer1([xyz | expr*1/3 | latent]) (NO activation); 3 x relu(Linear 256); feat = relu(fc_feat(x));
-    alpha = fc_alpha(x) (reads x, not feat); relu(layers_dir.0([feat | dirs])); rgb = fc_rgb."""
+    alpha = fc_alpha(x) (reads x, not feat); relu(layers_dir.0([feat | dirs])); rgb = fc_rgb.
+    Test hooks as in paper_mlp: `masks` (5 boolean tensors: layers_xyz.0..2, fc_feat, layers_dir.0) replaces each ReLU by a
+    multiplication with the given mask; `acts` (a list) collects layer1's output and the 5 post-ReLU activations."""
     n = x87.shape[0]
     xyz, dirs = x87[:, :63], x87[:, 63:]
     e = (expr * 1 / 3).reshape(1, -1).repeat(n, 1)
     l = latent.reshape(1, -1).repeat(n, 1)
+    k = [0]
+
+    def act(v):
+        out = torch.relu(v) if masks is None else v * masks[k[0]].to(v.dtype)
+        k[0] += 1
+        if acts is not None:
+            acts.append(out)
+        return out
+
     x = _lin(torch.cat((xyz, e, l), dim=1), p, "layer1")
+    if acts is not None:
+        acts.append(x)
     for i in range(3):
-        x = torch.relu(_lin(x, p, f"layers_xyz.{i}"))
-    feat = torch.relu(_lin(x, p, "fc_feat"))
+        x = act(_lin(x, p, f"layers_xyz.{i}"))
+    feat = act(_lin(x, p, "fc_feat"))
     alpha = _lin(x, p, "fc_alpha")
-    h = torch.relu(_lin(torch.cat((feat, dirs), dim=-1), p, "layers_dir.0"))
+    h = act(_lin(torch.cat((feat, dirs), dim=-1), p, "layers_dir.0"))
     return torch.cat((_lin(h, p, "fc_rgb"), alpha), dim=-1)
 
 

@@ -1,5 +1,5 @@
-"""Second model family (ConditionalBlendshapeLearnableCodeNeRFModel): inference parity against the reference's golden
-output and the fp64 oracle.  GPU only."""
+"""Second model family (ConditionalBlendshapeLearnableCodeNeRFModel): inference and training parity against the reference's
+golden outputs / gradients and the fp64 oracle.  GPU only."""
 import os
 
 import numpy as np
@@ -40,12 +40,6 @@ def test_lcode_eval_against_golden_reference(hip_lib, gpu):
         d = np.abs(t.cpu().numpy() - gold[n])
         print(f"[lcode] {n}: max|d|={d.max():.3e}")
         assert d.max() <= TOL[n], (n, d.max())
-    # training this family is refused loudly, not silently mis-computed
-    lat = c["latent"].to(gpu).requires_grad_(True)
-    with pytest.raises(NotImplementedError):
-        nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train", encode_position_fn=ex,
-                                  encode_direction_fn=ed, expressions=c["expr"].to(gpu), background_prior=c["bg"].to(gpu),
-                                  latent_code=lat)
 
 
 def test_lcode_mlp_vs_fp64_oracle(hip_lib, gpu):
@@ -64,3 +58,94 @@ def test_lcode_mlp_vs_fp64_oracle(hip_lib, gpu):
     scale = ref.abs().amax(dim=(0, 1))
     print("lcode mlp err", err.tolist(), "scale", scale.tolist())
     assert torch.all(err <= 2e-5 * scale + 2e-5)
+
+
+def rel_l2(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+LC_SAVED = dict(pe=(0, 64), l1=(64, 256), x0=(320, 256), x1=(576, 256), x2=(832, 256), feat=(1088, 256), dir=(1344, 128), dirf=(1472, 16))
+LC_RELU = ["x0", "x1", "x2", "feat", "dir"]
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
+def test_lcode_mlp_bwd_vs_fp64_oracle(hip_lib, gpu, n_rays, s):
+    """MLP-level gradients (all 16 tensors + latent) against fp64 autograd of the oracle evaluated at the ReLU masks the
+    HIP forward saw; the saved activations against the free-running fp64 oracle."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    g = torch.Generator().manual_seed(23)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 9, n_rays, 23)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    d_raw = torch.randn((n_rays, s, 4), generator=g)
+    p = O.init_lcode_params(6)
+    m = lmodel(nerf, p, gpu)
+    args = (ro.to(gpu), rd.to(gpu), z.to(gpu), rd.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    raw_e, _ = m.hip_forward(*args, False)
+    raw_t, state = m.hip_forward(*args, True)
+    assert torch.equal(raw_t, raw_e)                       # training forward == eval forward, bit for bit
+    grads, g_lat = m.hip_backward(state, z.to(gpu), d_raw.to(gpu))
+    n_pts = n_rays * s
+    sv = state[2].cpu()
+    sec = lambda k: sv[LC_SAVED[k][0] * n_pts:(LC_SAVED[k][0] + LC_SAVED[k][1]) * n_pts].view(n_pts, LC_SAVED[k][1])
+
+    def oracle(masks):
+        pp = {k: v.double().clone().requires_grad_(True) for k, v in p.items()}
+        lat = c["latent"].double().clone().requires_grad_(True)
+        acts = []
+        out = O.lcode_mlp(pp, O.encode_points(ro.double(), rd.double(), z.double(), O.NEAR, O.FAR), c["expr"].double(), lat,
+                          masks=masks, acts=acts)
+        out.backward(d_raw.reshape(-1, 4).double())
+        return pp, lat, acts
+    _, _, acts_free = oracle(None)
+    flips = 0
+    for name, a in zip(["l1"] + LC_RELU, acts_free):
+        got = sec(name)
+        assert (got.double() - a).abs().max() < 1e-4 * (1 + float(a.detach().abs().max())), name
+        if name != "l1":
+            flips += int(((got > 0) != (a > 0)).sum())
+    masks = [sec(k) > 0 for k in LC_RELU]
+    assert flips <= 1e-5 * sum(mk.numel() for mk in masks) + 2
+    pp, lat, _ = oracle(masks)
+    worst = 0.0
+    for k, gh in zip(nerf.models.LCODE_KEYS, grads):
+        e = rel_l2(gh.cpu(), pp[k].grad)
+        worst = max(worst, e)
+        assert e < 1e-4, (k, e)                            # north-star gate for gradients: rel L2 <= 1e-4 per tensor
+    e = rel_l2(g_lat.cpu(), lat.grad)
+    print(f"lcode mlp bwd ({n_rays}x{s}): worst param rel L2 {worst:.2e}, latent {e:.2e}, mask flips {flips}")
+    assert e < 1e-4
+
+
+def test_lcode_train_step_vs_reference_gradients(hip_lib, gpu):
+    """Full training step (coarse + fine, perturb, noise, latent regulariser) through run_one_iter_of_nerf + autograd against
+    the gradients the reference's autograd produced (tests/golden/lcode_train_rand_64_64_grads.npz)."""
+    import nerf
+    gold = np.load(os.path.join(GOLD, "lcode_train_rand_64_64_grads.npz"))
+    c = C.build_case("train_rand_64_64")
+    mc, mf = lmodel(nerf, O.init_lcode_params(5), gpu), lmodel(nerf, O.init_lcode_params(6), gpu)
+    opt = U.make_options(nerf, 64, 64, True, c["noise_std"], 65536)
+    ex, ed = U.encoders(nerf)
+    latent = c["latent"].clone().to(gpu).requires_grad_(True)
+    rands, randns = U.case_random_lists(c)
+    with torch.enable_grad(), U.injected_random(rands, randns):
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                        background_prior=c["bg"].to(gpu), latent_code=latent)
+        loss = O.train_loss(out[0], out[3], c["tgt"].to(gpu), latent)
+        loss.backward()
+    assert np.abs(out[0].detach().cpu().numpy() - gold["rgb_c"]).max() < 5e-6
+    assert abs(float(loss) - float(gold["loss"])) < 2e-6
+    # the fine pass resamples at depths that depend on coarse weights to fp32 rounding, and the x300 density head amplifies
+    # that into the gradient: the comparison with the reference is therefore a few 1e-3 (the MLP-level test above, on
+    # identical inputs and masks, holds 1e-4)
+    assert np.abs(latent.grad.cpu().numpy() - gold["latent"]).max() < 5e-3 * np.abs(gold["latent"]).max()
+    for tag, m in (("coarse", mc), ("fine", mf)):
+        for k, v in m.named_parameters():
+            assert v.grad is not None and bool(torch.isfinite(v.grad).all()), (tag, k)
+            want = float(gold[f"norm:{tag}.{k}"])
+            assert abs(float(v.grad.double().norm()) - want) <= 5e-3 * want + 1e-9, (tag, k, float(v.grad.double().norm()), want)
+            head = gold[f"head:{tag}.{k}"]
+            got = v.grad.reshape(-1)[:257].cpu().numpy()
+            assert np.abs(got - head).max() <= 5e-3 * np.abs(head).max() + 1e-9, (tag, k)

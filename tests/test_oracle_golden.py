@@ -107,6 +107,26 @@ def test_gradient_fixture():
             assert abs(float(v.grad.double().norm()) - want) <= 1e-4 * want + 1e-9, (tag, k)
 
 
+def test_lcode_gradient_fixture():
+    """Second model family: oracle autograd (fp32) vs the reference's autograd on the training case."""
+    c = C.build_case("train_rand_64_64")
+    g = np.load(os.path.join(GOLD, "lcode_train_rand_64_64_grads.npz"))
+    pc = {k: v.clone().requires_grad_(True) for k, v in O.init_lcode_params(5).items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in O.init_lcode_params(6).items()}
+    lat = c["latent"].clone().requires_grad_(True)
+    out = O.render_rays(pc, pf, c["ro"], c["rd"], c["expr"], lat, c["bg"], O.NEAR, O.FAR, 64, 64, t_rand=c["t_rand"],
+                        noise_c=c["noise_c"], u=c["u"], noise_f=c["noise_f"], mlp=O.lcode_mlp)
+    assert np.abs(out[0].detach().numpy() - g["rgb_c"]).max() < 1e-6 and np.abs(out[3].detach().numpy() - g["rgb_f"]).max() < 1e-5
+    loss = O.train_loss(out[0], out[3], c["tgt"], lat)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    assert np.abs(lat.grad.numpy() - g["latent"]).max() < 1e-6 * max(1.0, np.abs(g["latent"]).max())
+    for tag, p in (("coarse", pc), ("fine", pf)):
+        for k, v in p.items():
+            want = float(g[f"norm:{tag}.{k}"])
+            assert abs(float(v.grad.double().norm()) - want) <= 1e-4 * want + 1e-9, (tag, k)
+
+
 @pytest.mark.skipif(not RI.reference_available(), reason="/root/reference only exists in the build container")
 def test_oracle_equals_live_reference():
     from oracle import make_golden as MG
