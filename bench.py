@@ -47,14 +47,14 @@ INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
 NEAR, FAR = 0.2, 0.8
 
 
-def synth_params(seed, device):
+def synth_params(seed, device, family="paper"):
     """Random-init weights of the paper architecture (torch default nn.Linear init) with a density boost so
-    that rays are neither all-empty nor all-opaque."""
+    that rays are neither all-empty nor all-opaque.  family="lcode": the second model family (--mode train only)."""
     import nerf
     torch.manual_seed(seed)
-    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
-                                                        include_input_dir=False, use_viewdirs=True, num_layers=4,
-                                                        hidden_size=256, include_expression=True)
+    cls = nerf.models.ConditionalBlendshapePaperNeRFModel if family == "paper" else nerf.models.ConditionalBlendshapeLearnableCodeNeRFModel
+    m = cls(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True,
+            num_layers=4, hidden_size=256, include_expression=True)
     with torch.no_grad():
         m.fc_alpha.weight.mul_(1000.0)
         m.fc_alpha.bias.fill_(5.0)
@@ -198,10 +198,12 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32", "data": "synthetic",
-            "config": {"workload": "configs[2]: paper-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
+            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if (args.precision == "bf16x3" and args.family == "paper") else "f32",
+            "data": "synthetic",
+            "config": {"workload": f"configs[2]: {args.family}-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
                                    "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
-                       "rays_per_step": n_rays * world, "parallelism": f"dp{world}", "mlp_precision": args.precision}}), flush=True)
+                       "rays_per_step": n_rays * world, "parallelism": f"dp{world}",
+                       "mlp_precision": args.precision if args.family == "paper" else "f32", "family": args.family}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -217,6 +219,8 @@ def main():
                     help="inference GEMM arithmetic: bf16x3 = split-bf16 (3 bf16 MFMAs per product, f32 accumulate; passes the "
                          "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
     ap.add_argument("--chunksize", type=int, default=CHUNK, help="validation ray chunk (shipped configs: 65536)")
+    ap.add_argument("--family", choices=["paper", "lcode"], default="paper",
+                    help="train mode only: lcode = ConditionalBlendshapeLearnableCodeNeRFModel (exact-f32 kernels)")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=12288)
@@ -244,7 +248,9 @@ def main():
     from nerf import ops
     nerf.set_mlp_precision(args.precision)
 
-    model_c, model_f = synth_params(0, dev), synth_params(1, dev)
+    if args.family != "paper" and args.mode != "train":
+        raise SystemExit("--family lcode is a --mode train option (the eval line is BASELINE.json's paper-model metric)")
+    model_c, model_f = synth_params(0, dev, args.family), synth_params(1, dev, args.family)
     if args.mode == "train":
         return bench_train(args, nerf, model_c, model_f, dev, rank, world, dist)
     opt = options(nerf, args.chunksize)
