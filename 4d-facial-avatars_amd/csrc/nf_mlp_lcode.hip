@@ -64,7 +64,8 @@ static std::mutex g_lcode_mutex;
 static uint32_t* g_lcode_table[64] = {nullptr};
 
 extern "C" size_t nf_lcode_packed_floats(void) { return (size_t)nlc::PACKED; }
-extern "C" size_t nf_lcode_cond_floats(void) { return (size_t)nlc::COND_FLOATS; }
+// padded to 10 KiB: the split-bf16 kernel stages the table into LDS with ten 1-KiB DMA pieces
+extern "C" size_t nf_lcode_cond_floats(void) { return 2560; }
 
 extern "C" int nf_lcode_pack(const float* const* params, float* packed, nf_stream_t stream) {
     if (!params || !packed) return NF_EINVAL;

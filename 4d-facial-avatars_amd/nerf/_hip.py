@@ -52,6 +52,9 @@ _PROTOTYPES = {
     "nf_lcode_pack": (C.c_int, [_P, _P, _P]),
     "nf_lcode_condition": (C.c_int, [_P, _P, _P, _F, _F, _P, _P]),
     "nf_lcode_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_lcode_packed_bf16_bytes": (_Z, []),
+    "nf_lcode_pack_bf16": (C.c_int, [_P, _P, _P]),
+    "nf_lcode_mlp_fwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "nf_lcode_saved_floats": (_Z, [_L]),
     "nf_lcode_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_floats": (_Z, []),

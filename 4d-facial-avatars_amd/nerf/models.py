@@ -157,6 +157,8 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         self._sig = None
         self._packed_t = None
         self._sig_t = None
+        self._packed_b = None
+        self._sig_b = None
 
     def fused_supported(self) -> bool:
         return (self.use_viewdirs and self.dim_xyz == 63 and self.dim_dir == 24 and self.dim_expression == 76
@@ -181,6 +183,21 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                 H.check(lib.nf_lcode_pack(arr, H.ptr(self._packed), H.stream_ptr(dev)), "nf_lcode_pack")
             self._sig = sig
         return self._packed
+
+    def _hip_packed_bf16(self):
+        import ctypes as C
+        from . import _hip as H
+        ps = self.hip_param_list()
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        if self._packed_b is None or sig != self._sig_b:
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            self._packed_b = torch.empty(lib.nf_lcode_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_lcode_pack_bf16(arr, H.ptr(self._packed_b), H.stream_ptr(dev)), "nf_lcode_pack_bf16")
+            self._sig_b = sig
+        return self._packed_b
 
     def _hip_packed_t(self):
         import ctypes as C
@@ -210,8 +227,13 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             H.check(lib.nf_lcode_condition(H.ptr(packed), H.ptr(expr), H.ptr(latent), float(np.float32(near)), float(np.float32(far)),
                                            H.ptr(cond), H.stream_ptr(dev)), "nf_lcode_condition")
             if not need_grad:
-                H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
-                                             n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
+                from . import ops
+                if ops.get_mlp_precision() == "bf16x3":      # split-bf16 inference kernel; training of this family stays exact f32
+                    H.check(lib.nf_lcode_mlp_fwd_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
+                                                      H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_bf16")
+                else:
+                    H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                                 n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
                 return raw, None
             saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
             H.check(lib.nf_lcode_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,

@@ -139,6 +139,14 @@ int nf_lcode_condition(const float* packed, const float* expr76, const float* la
                        float* cond, nf_stream_t stream);
 int nf_lcode_mlp_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                      const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+/* The same inference forward in split-bf16 arithmetic (see nf_paper_mlp_fwd_bf16): stream of
+ * nf_lcode_packed_bf16_bytes() bytes packed from the same 16 tensors; `cond` as filled by nf_lcode_condition.          */
+size_t nf_lcode_packed_bf16_bytes(void);
+int nf_lcode_pack_bf16(const float* const* params, void* packed_bf16, nf_stream_t stream);
+int nf_lcode_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
+                          const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                          nf_stream_t stream);
+
 /* Training of the same family, exact f32 (autograd through M:590-636 as the trainer drives it, TR:355-392):
  * forward that also fills `saved` (nf_lcode_saved_floats(n_rays*n_samples) floats), transposed weight image, and the
  * backward: grads = the 16 tensors in the order of nerf.models.LCODE_KEYS (layer1, layers_xyz.0..2, layers_dir.0,

@@ -149,3 +149,57 @@ def test_lcode_train_step_vs_reference_gradients(hip_lib, gpu):
             head = gold[f"head:{tag}.{k}"]
             got = v.grad.reshape(-1)[:257].cpu().numpy()
             assert np.abs(got - head).max() <= 5e-3 * np.abs(head).max() + 1e-9, (tag, k)
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (5, 192), (1, 1), (40, 192)])
+def test_lcode_bf16x3_mlp_vs_oracle(hip_lib, gpu, n_rays, s):
+    """Split-bf16 inference kernel of the second family against the fp64 oracle (and next to the exact-f32 kernel)."""
+    import nerf
+    c = C.build_case("eval_det_64_128")
+    g = torch.Generator().manual_seed(5)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 3, n_rays, 5)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    p = O.init_lcode_params(6)
+    m = lmodel(nerf, p, gpu)
+    args = (ro.to(gpu), rd.to(gpu), z.to(gpu), rd.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR, False)
+    raw_f = m.hip_forward(*args)[0].cpu()
+    nerf.set_mlp_precision("bf16x3")
+    try:
+        raw_b = m.hip_forward(*args)[0].cpu()
+    finally:
+        nerf.set_mlp_precision("f32")
+    p64 = {k: v.double() for k, v in p.items()}
+    ref = O.lcode_mlp(p64, O.encode_points(ro.double(), rd.double(), z.double(), O.NEAR, O.FAR), c["expr"].double(),
+                      c["latent"].double()).reshape(n_rays, s, 4)
+    scale = ref.abs().amax(dim=(0, 1))
+    eb = (raw_b.double() - ref).abs().amax(dim=(0, 1))
+    ef = (raw_f.double() - ref).abs().amax(dim=(0, 1))
+    print(f"lcode bf16x3 max err {eb.tolist()}  f32 max err {ef.tolist()}  scale {scale.tolist()}")
+    assert torch.all(eb <= 3e-4 * scale + 1e-5)
+
+
+def test_lcode_bf16x3_psnr_gate_and_golden(hip_lib, gpu):
+    """The north-star gate with the split-bf16 kernel of the second family: |PSNR(ours,tgt) - PSNR(reference,tgt)| <= 1e-4 dB
+    on the reference's own golden output (rendered rays of the eval case), plus the per-output tolerances."""
+    import nerf
+    gold = np.load(os.path.join(GOLD, "lcode_eval_det_64_128.npz"))
+    c = C.build_case("eval_det_64_128")
+    mc, mf = lmodel(nerf, O.init_lcode_params(5), gpu), lmodel(nerf, O.init_lcode_params(6), gpu)
+    opt = U.make_options(nerf, 64, 128, False, 0.0)
+    ex, ed = U.encoders(nerf)
+    nerf.set_mlp_precision("bf16x3")
+    try:
+        with torch.no_grad():
+            out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train",
+                                            encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                            background_prior=c["bg"].to(gpu), latent_code=c["latent"].to(gpu))
+    finally:
+        nerf.set_mlp_precision("f32")
+    tol = dict(TOL, rgb_c=3e-5, disp_c=1e-4)
+    for n, t in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"], out):
+        d = np.abs(t.cpu().numpy() - gold[n])
+        assert d.max() <= tol[n], (n, d.max())
+    for k, name in ((0, "rgb_c"), (3, "rgb_f")):
+        p_ref, p_our = O.psnr(torch.from_numpy(gold[name]), c["tgt"]), O.psnr(out[k].cpu(), c["tgt"])
+        print(f"lcode bf16x3 {name}: PSNR ref {p_ref:.6f} ours {p_our:.6f} |d|={abs(p_ref - p_our):.2e} dB")
+        assert abs(p_ref - p_our) <= 1e-4

@@ -1,0 +1,17 @@
+import sys, time, torch
+sys.path.insert(0, "4d-facial-avatars_amd"); sys.path.insert(0, ".")
+import nerf
+from oracle import nerface_oracle as O
+dev = torch.device("cuda:0")
+m = nerf.models.ConditionalBlendshapeLearnableCodeNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True, num_layers=4, hidden_size=256, include_expression=True)
+m.load_state_dict(O.init_lcode_params(6)); m = m.to(dev)
+R, S = 65536, 192
+ro = torch.zeros(R, 3, device=dev); rd = torch.randn(R, 3, device=dev) * 0.3; z = torch.sort(torch.rand(R, S, device=dev) * 0.6 + 0.2, dim=-1)[0]
+expr = torch.randn(76, device=dev); lat = torch.randn(32, device=dev) * 0.1
+for prec in ("f32", "bf16x3"):
+    nerf.set_mlp_precision(prec)
+    for _ in range(2): m.hip_forward(ro, rd, z, rd, expr, lat, 0.2, 0.8, False)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(3): m.hip_forward(ro, rd, z, rd, expr, lat, 0.2, 0.8, False)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t) / 3
+    print(f"lcode {prec} {R}x{S}: {dt*1e3:.2f} ms  {R*S*684800/dt/1e12:.1f} TFLOP/s algorithmic")
