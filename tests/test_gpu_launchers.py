@@ -53,6 +53,36 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     assert os.path.exists(os.path.join(out, "disparity", "0002.png"))
 
 
+def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
+    """The same two launchers with `type: ConditionalBlendshapeLearnableCodeNeRFModel` in the config (as 6 shipped configs
+    have): trains (exact-f32 kernels), checkpoints with this family's state_dict keys, renders in both precisions."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
+    import make_synthetic_dataset as MS
+    from launch import eval_sharded, train_sharded
+    from oracle import nerface_oracle as O
+    from PIL import Image
+    base = str(tmp_path)
+    MS.write(os.path.join(base, "data"))
+    cfg_path = os.path.join(base, "config.yml")
+    with open(cfg_path, "w") as f:
+        yaml.safe_dump(MS.config(os.path.join(base, "data"), os.path.join(base, "logs"),
+                                 model_type="ConditionalBlendshapeLearnableCodeNeRFModel"), f)
+    logdir = train_sharded.main(["--config", cfg_path])
+    ck0 = torch.load(os.path.join(logdir, "checkpoint00000.ckpt"), map_location="cpu")
+    ck = torch.load(os.path.join(logdir, "checkpoint00005.ckpt"), map_location="cpu")
+    assert list(ck["model_fine_state_dict"].keys()) == O.LCODE_KEYS
+    moved = [k for k in O.LCODE_KEYS if not torch.equal(ck["model_fine_state_dict"][k], ck0["model_fine_state_dict"][k])]
+    assert len(moved) == len(O.LCODE_KEYS), set(O.LCODE_KEYS) - set(moved)        # every tensor of the family receives gradients
+    assert float(ck["latent_codes"].abs().sum()) > 0 and np.isfinite(float(ck["loss"]))
+    for prec in ("f32", "bf16x3"):
+        out = os.path.join(base, "render_" + prec)
+        assert eval_sharded.main(["--config", cfg_path, "--checkpoint", os.path.join(logdir, "checkpoint00005.ckpt"), "--savedir", out,
+                                  "--precision", prec]) == [0, 1, 2]
+        a = np.asarray(Image.open(os.path.join(out, "0001.png")))
+        assert a.shape == (32, 32, 3) and a.std() > 0
+
+
 def test_eval_postprocess_matches_oracle(hip_lib, gpu):
     from nerf import ops
     from oracle import nerface_oracle as O

@@ -40,8 +40,8 @@ def write(basedir, size=32, n_train=6, n_val=2, n_test=3, seed=0):
     return basedir
 
 
-def config(basedir, logdir, train_iters=6, num_random_rays=256):
-    model = dict(type="ConditionalBlendshapePaperNeRFModel", num_layers=4, hidden_size=256, skip_connect_every=3, include_input_xyz=True,
+def config(basedir, logdir, train_iters=6, num_random_rays=256, model_type="ConditionalBlendshapePaperNeRFModel"):
+    model = dict(type=model_type, num_layers=4, hidden_size=256, skip_connect_every=3, include_input_xyz=True,
                  log_sampling_xyz=True, num_encoding_fn_xyz=10, use_viewdirs=True, include_input_dir=False, num_encoding_fn_dir=4,
                  log_sampling_dir=True)
     mode = dict(num_random_rays=num_random_rays, chunksize=2048, perturb=True, num_coarse=64, num_fine=64, white_background=False,
