@@ -27,6 +27,14 @@ def to_uint8(img: torch.Tensor) -> np.ndarray:
 
 
 def main(argv=None):
+    keep = nerf.get_mlp_precision()          # the precision switch is process-global: leave it as the caller had it
+    try:
+        return _main(argv)
+    finally:
+        nerf.set_mlp_precision(keep)
+
+
+def _main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, required=True)
     ap.add_argument("--checkpoint", type=str, required=True)

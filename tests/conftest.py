@@ -32,3 +32,15 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.fail("a test marked gpu is running without a ROCm device")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _default_mlp_precision():
+    """nerf.set_mlp_precision is process-global; every test starts from (and leaves) the library default, exact f32."""
+    nerf_mod = sys.modules.get("nerf")
+    if nerf_mod is not None and hasattr(nerf_mod, "set_mlp_precision"):
+        nerf_mod.set_mlp_precision("f32")
+    yield
+    nerf_mod = sys.modules.get("nerf")
+    if nerf_mod is not None and hasattr(nerf_mod, "set_mlp_precision"):
+        nerf_mod.set_mlp_precision("f32")
