@@ -41,6 +41,7 @@ N_COARSE, N_FINE = 64, 128
 CHUNK = 65536
 FLOP_PER_POINT = 1_100_032            # algorithmic forward FLOPs of the paper MLP per point
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3 TB/s is achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
 BF16X3_EXEC_FLOP_PER_POINT = 3012 * 32768 / 32   # executed MFMA FLOPs per point of the split-bf16 kernel (3012 MFMAs / 32 points)
 INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
@@ -129,6 +130,54 @@ def cpu_baseline(n_rays=12288):
             "parity_on_sample": parity}
 
 
+# algorithmic HBM bytes per MLP point of the three training kernels (csrc/nf_mlp_layout.h, nf_mlp_lcode_layout.h): the forward
+# writes the saved activations (+ ReLU bit masks in split-bf16), the chain reads its ReLU gates (+ d_raw) and writes dZ, the
+# weight-gradient GEMMs read every saved activation, every dZ and d_raw once
+TRAIN_BYTES_PER_POINT = {
+    ("paper", "bf16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
+    ("paper", "f32"): 4 * 2256 + (4 * (6 * 256 + 3 * 128) + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
+    ("lcode", "f32"): 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+}
+
+
+def train_roofline(args, model, dev, n_rays):
+    """HBM roofline of the training MLP kernels, measured live with events on the stream they are launched on (torch's current
+    stream): training forward + backward (chain, dW GEMMs, reduction) of one model at the two launch sizes of an iteration
+    (n_rays x 64 coarse, n_rays x 128 fine), algorithmic bytes / time against the 8 TB/s HBM peak."""
+    g = torch.Generator(device="cpu").manual_seed(5)
+    ro = torch.zeros(n_rays, 3).to(dev)
+    rd = (torch.randn(n_rays, 3, generator=g) * 0.3).to(dev)
+    expr, lat = (torch.randn(76, generator=g) * 0.5).to(dev), (torch.randn(32, generator=g) * 0.1).to(dev)
+    total_ms, total_pts = 0.0, 0
+    for s in (64, 128):
+        z = torch.sort(torch.rand(n_rays, s, generator=g) * 0.6 + 0.2, dim=-1)[0].to(dev)
+        d_raw = (torch.randn(n_rays, s, 4, generator=g) / (3 * n_rays)).to(dev)
+        def once():
+            raw, state = model.hip_forward(ro, rd, z, rd, expr, lat, NEAR, FAR, True)
+            model.hip_backward(state, z, d_raw)
+        for _ in range(3):
+            once()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 10
+        e0.record()
+        for _ in range(reps):
+            once()
+        e1.record()
+        torch.cuda.synchronize()
+        total_ms += e0.elapsed_time(e1) / reps
+        total_pts += n_rays * s
+    prec = args.precision if args.family == "paper" else "f32"
+    bpp = TRAIN_BYTES_PER_POINT[(args.family, prec)]
+    achieved = bpp * total_pts / (total_ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": f"{args.family} MLP training kernels of ONE model per iteration (training forward + dX chain + dW GEMMs "
+                                      f"+ reduction; {n_rays} x 64 and {n_rays} x 128 points)",
+            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
+            "algorithmic_bytes_per_point": bpp, "ms_both_launches": total_ms,
+            "note": "per iteration the coarse model runs the 64-sample launch and the fine model the 128-sample launch, so "
+                    "ms_both_launches is the MLP-kernel time of one iteration; a dedicated rocprofv3 pass (profiles/) gives the "
+                    "per-kernel split and the PMC HBM bytes"}
+
+
 def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
     """configs[2] / configs[4]: the trainer's iteration (TR:289-400) on synthetic data -- full-frame ray bundle, 2048 random
     rays, run_one_iter_of_nerf(mode='train') with the shipped training settings (64+64, chunksize 2048, perturb, noise
@@ -193,8 +242,10 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert bool(torch.isfinite(loss))
+    roofline = train_roofline(args, model_f, dev, n_rays) if rank == 0 else None
     if rank == 0:
         print(json.dumps({
+            "roofline": roofline,
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
