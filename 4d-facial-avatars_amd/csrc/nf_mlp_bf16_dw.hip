@@ -21,6 +21,7 @@
 #include <mutex>
 
 #include "nf_mlp_bf16_common.h"
+#include "nf_mlp_lcode_layout.h"
 
 struct NfbDwSeg {
     int kind;      // 0: dz section, 1: d_raw, 2: saved section
@@ -45,11 +46,87 @@ struct NfbDwJob {
     NfbDwProd prod[NFB_DW_WAVES];
 };
 
-#define NFB_DW_JOBS 12
+#define NFB_DW_JOBS 12                                   // paper model
+#define NFB_DW_JOBS_LCODE 8                              // second model family
 #define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
 #define NFB_DW_NSET 3                                    // register sets of raw tiles: 2 stages of loads in flight
 #define NFB_DW_CVT_U4 (NFB_DW_MAX_TILES * 128)           // 16-byte units: per tile 64 lanes x (hi, lo)
 __constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
+__constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
+
+// job-table builder helpers (host)
+struct NfbDwBuilder {
+    NfbDwJob* jobs;
+    int nj = 0;
+    int first_tile[4];
+    NfbDwJob& new_job() {
+        NfbDwJob& j = jobs[nj++];
+        j.nseg = j.ntile = 0;
+        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0};
+        for (auto& t : j.tile) t = NfbDwTile{0, 0, -1};
+        for (auto& p : j.prod) p = NfbDwProd{0, 0, 0, 0, 0, 0, 0, 0};   // idle wave: multiplies tiles 0, 1 and stores nothing
+        return j;
+    }
+    // segment + its tiles; cs >= 0: slab offset of the column sums of the section
+    int add_seg(NfbDwJob& j, int kind, int sec, int width, int cs) {
+        j.seg[j.nseg] = NfbDwSeg{kind, sec, width};
+        first_tile[j.nseg] = j.ntile;
+        for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
+        return j.nseg++;
+    }
+    // rows [a0, a0 + a_valid) of segment sa  x  columns [b0, b0 + b_valid) of segment sb   (a0, b0 multiples of 32)
+    NfbDwProd prod(int sa, int a0, int a_valid, int sb, int b0, int b_valid, int out_off, int ldo) const {
+        return NfbDwProd{(a_valid + 31) / 32, (b_valid + 31) / 32, first_tile[sa] + a0 / 32, first_tile[sb] + b0 / 32,
+                         a_valid, b_valid, out_off, ldo};
+    }
+    // a 256 x 256 layer: 4 x 4 blocks of 64 x 64
+    void layer256(int zsec, int bsec, int gout, int cs) {
+        NfbDwJob& j = new_job();
+        const int sa = add_seg(j, 0, zsec, 256, cs), sb = add_seg(j, 2, bsec, 256, -1);
+        for (int w = 0; w < 16; ++w) {
+            const int ag = w >> 2, bg = w & 3;
+            j.prod[w] = prod(sa, 64 * ag, 64, sb, 64 * bg, 64, gout + 64 * ag * 256 + 64 * bg, 256);
+        }
+    }
+    // a 256-row dZ section against the 64 positional-encoding slots
+    void pe256(int zsec, int pesec, int gout, int cs) {
+        NfbDwJob& j = new_job();
+        const int sz = add_seg(j, 0, zsec, 256, cs), sp = add_seg(j, 2, pesec, 64, -1);
+        for (int w = 0; w < 8; ++w) j.prod[w] = prod(sz, 32 * w, 32, sp, 0, 64, gout + 32 * w * 64, 64);
+    }
+};
+
+// second model family (layouts: nf_mlp_lcode_layout.h)
+static void nfb_build_dw_jobs_lcode(NfbDwJob* jobs) {
+    using namespace nlc;
+    NfbDwBuilder b{jobs};
+    b.layer256(Z_X0, S_L1, G_X0, CS_L1 + 256);
+    b.layer256(Z_X1, S_X0, G_X1, CS_L1 + 512);
+    b.layer256(Z_X2, S_X1, G_X2, CS_L1 + 768);
+    b.layer256(Z_FEAT, S_X2, G_FEAT, CS_L1 + 1024);
+    b.pe256(Z_L1, S_PE, G_L1, CS_L1);
+    {   // dZ_dir x feat
+        NfbDwJob& j = b.new_job();
+        const int sz = b.add_seg(j, 0, Z_DIR, 128, CS_DIR), sf = b.add_seg(j, 2, S_FEAT, 256, -1);
+        for (int w = 0; w < 8; ++w) {
+            const int ag = w >> 2, bg = w & 3;
+            j.prod[w] = b.prod(sz, 64 * ag, 64, sf, 64 * bg, 64, G_DIRA + 64 * ag * 256 + 64 * bg, 256);
+        }
+    }
+    {   // d_raw x x2: row 3 (d sigma) = fc_alpha.weight gradient (fc_alpha reads x)
+        NfbDwJob& j = b.new_job();
+        const int sr = b.add_seg(j, 1, 0, 4, -1), sx = b.add_seg(j, 2, S_X2, 256, -1);
+        for (int bg = 0; bg < 4; ++bg) j.prod[bg] = b.prod(sr, 0, 4, sx, 64 * bg, 64, G_ALPHA + 64 * bg, 256);
+    }
+    {   // dZ_dir x dir features, d_raw x dir-layer output (fc_rgb.weight; the 4 output-bias gradients = column sums of d_raw)
+        NfbDwJob& j = b.new_job();
+        const int sz = b.add_seg(j, 0, Z_DIR, 128, -1), sd = b.add_seg(j, 2, S_DIRF, 16, -1), sr = b.add_seg(j, 1, 0, 4, CS_RGB);
+        const int s2 = b.add_seg(j, 2, S_DIR, 128, -1);
+        for (int ag = 0; ag < 2; ++ag) j.prod[ag] = b.prod(sz, 64 * ag, 64, sd, 0, 16, G_DIRB + 64 * ag * 16, 16);
+        for (int bg = 0; bg < 2; ++bg) j.prod[2 + bg] = b.prod(sr, 0, 4, s2, 64 * bg, 64, G_RGB + 64 * bg, 128);
+    }
+    // b.nj == NFB_DW_JOBS_LCODE by construction
+}
 
 static void nfb_build_dw_jobs(NfbDwJob* jobs) {
     using namespace nfl;
@@ -153,14 +230,15 @@ __device__ __forceinline__ void nfb_dw_load_tail(__amdgpu_buffer_rsrc_t rsrc, un
                                                                             (int)(j * stride_b), 0));
 }
 
+// MODEL selects the job table: 0 paper model, 1 second model family
+template <int MODEL>
 __global__ void __launch_bounds__(64 * NFB_DW_WAVES, 1)
 k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
-                     int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
-    using namespace nfl;
+                     int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs, int slab_floats) {
     __shared__ __attribute__((aligned(16))) uint4 lds_cvt[2 * NFB_DW_CVT_U4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
-    const NfbDwJob& job = c_dwb_jobs[blockIdx.x];
+    const NfbDwJob& job = MODEL ? c_dwb_jobs_lcode[blockIdx.x] : c_dwb_jobs[blockIdx.x];
     const NfbDwProd pr = job.prod[wave];
     const int slice = blockIdx.y;
     const int64_t p_begin = (int64_t)slice * pts_per_slice;
@@ -269,7 +347,7 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
     }
 
     // D of tile (t, u): lane (h, c), reg r -> row 32 t + (r & 3) + 8 (r >> 2) + 4 h, column 32 u + c
-    float* slab = slabs + (int64_t)slice * SLAB_FLOATS;
+    float* slab = slabs + (int64_t)slice * slab_floats;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -289,8 +367,8 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
 
 static std::once_flag g_dwb_once[64];
 
-// called by nf_paper_mlp_bwd_bf16 (nf_mlp_bwd.hip); slabs: n_slices x SLAB_FLOATS
-int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+// called by nf_paper_mlp_bwd_bf16 (nf_mlp_bwd.hip) / nf_lcode_mlp_bwd_bf16; slabs: n_slices x slab floats of the model
+int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
                        int n_slices, float* slabs, nf_stream_t stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
@@ -298,20 +376,28 @@ int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, 
     if (dev < 0 || dev >= 64) return NF_EINVAL;
     int rc = 0;
     std::call_once(g_dwb_once[dev], [&]() {
-        static NfbDwJob jobs[NFB_DW_JOBS];
+        static NfbDwJob jobs[NFB_DW_JOBS], jobs_l[NFB_DW_JOBS_LCODE];
         nfb_build_dw_jobs(jobs);
+        nfb_build_dw_jobs_lcode(jobs_l);
         hipError_t ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs), jobs, sizeof(jobs));
+        if (ee == hipSuccess) ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs_lcode), jobs_l, sizeof(jobs_l));
         if (ee != hipSuccess) rc = (int)ee;
     });
     if (rc) return rc;
-    hipLaunchKernelGGL(k_paper_dw_gemm_bf16, dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream), dz, d_raw, saved,
-                       n_points, pts_per_slice, slabs);
+    if (model == 0)
+        hipLaunchKernelGGL((k_paper_dw_gemm_bf16<0>), dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream), dz,
+                           d_raw, saved, n_points, pts_per_slice, slabs, (int)nfl::SLAB_FLOATS);
+    else
+        hipLaunchKernelGGL((k_paper_dw_gemm_bf16<1>), dim3(NFB_DW_JOBS_LCODE, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0,
+                           nf_s(stream), dz, d_raw, saved, n_points, pts_per_slice, slabs, (int)nlc::SLAB_FLOATS);
     NF_RETURN_LAUNCH();
 }
 
-// slices for the split-bf16 dW kernel: 12 bundles x 42 slices = 504 workgroups = two rounds of the 256 CUs
-void nfb_dw_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
-    int64_t pps = (n_points + 41) / 42;
+// slices for the split-bf16 dW kernel: about 504 workgroups = two rounds of the 256 CUs (paper: 12 bundles x 42 slices,
+// second family: 8 bundles x 63 slices)
+void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
+    const int target = model == 0 ? 42 : 63;
+    int64_t pps = (n_points + target - 1) / target;
     pps = (pps + 15) / 16 * 16;
     if (pps < 256) pps = 256;
     *pts_per_slice = pps;

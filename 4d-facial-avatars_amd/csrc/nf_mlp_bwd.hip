@@ -315,14 +315,14 @@ static const int NF_PARAM_NUMEL[NF_PAPER_NUM_PARAMS] = {
 extern "C" size_t nf_paper_grad_floats(void) { return (size_t)nfl::GRAD_FLOATS; }
 
 // defined in nf_mlp_bf16_dw.hip
-void nfb_dw_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices);
-int nfb_launch_dw_gemm(const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices);
+int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
                        int n_slices, float* slabs, nf_stream_t stream);
 
 extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
     nf_bwd_plan(n_points, &pps, &ns);
-    nfb_dw_plan(n_points, &pps, &ns_b);
+    nfb_dw_plan(0, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
     return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS;
 }
@@ -349,7 +349,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     const int rcj = g_paper_jobs.get(NF_DW_JOBS, nf_build_dw_jobs, &jobs);
     if (rcj) return rcj;
     int64_t pps; int ns;
-    if (split_dw) nfb_dw_plan(n_points, &pps, &ns);
+    if (split_dw) nfb_dw_plan(0, n_points, &pps, &ns);
     else nf_bwd_plan(n_points, &pps, &ns);
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
@@ -369,7 +369,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
                            n_points, dz);
     }
     if (split_dw) {
-        const int rc3 = nfb_launch_dw_gemm(dz, d_raw, saved, n_points, pps, ns, slabs, stream);
+        const int rc3 = nfb_launch_dw_gemm(0, dz, d_raw, saved, n_points, pps, ns, slabs, stream);
         if (rc3) return rc3;
     } else {
         hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,

@@ -1,0 +1,212 @@
+// B1 of the second model family on the bf16 matrix pipe: the backward chain of nf_mlp_lcode_bwd.hip as split-bf16 (3 bf16
+// MFMAs per product, f32 accumulate), the mirror image of nf_mlp_lcode_bf16_kernel.inc on a TRANSPOSED (hi, lo) weight stream;
+// same structure as nf_mlp_bf16_bwd.hip (paper model).  ReLU gates come from the bit masks the split-bf16 training forward
+// wrote (nlc::S_MASK); every dZ is written to HBM in f32 for the weight-gradient GEMMs.
+//   0 fc_rgb^T (3 -> 128)   1 layers_dir.0[:, :256]^T (128 -> 256)   2 [fc_feat ; fc_alpha]^T (256 + 1 -> 256)
+//   3 layers_xyz.2^T   4 layers_xyz.1^T   5 layers_xyz.0^T (-> dZ of layer1, which has no activation)
+#include <vector>
+#include <mutex>
+#include "nf_common.h"
+#include "nf_mlp_lcode_layout.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+namespace nfb {
+constexpr int NL = 6;
+constexpr int KS[NL] = {2, 8, 18, 16, 16, 16};
+constexpr int NO[NL] = {4, 8, 8, 8, 8, 8};
+constexpr int pair_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += KS[i] * NO[i]; return o; }
+constexpr int N_PAIRS = pair_off(NL);
+constexpr int STREAM_BF16 = N_PAIRS * 2 * 512;
+__host__ __device__ constexpr int hid_feature(int s, int h, int j) { return 16 * s + 4 * h + (j & 3) + 8 * (j >> 2); }
+}  // namespace nfb
+
+#include "nf_mlp_bf16_machinery.inc"
+
+// =================================================================================================
+// transposed (hi, lo) stream: block (s, nt), lane (h', i), j  ->  W[row = reduction feature(s, h', j)][col = 32 nt + i]
+// =================================================================================================
+struct NfLcodePtrsBT { const float* p[nlc::NPARAMS]; };
+
+static void nf_lcode_table_bf16_t(std::vector<uint32_t>& t) {
+    using namespace nfb;
+    const uint32_t Z = 0xFF000000u;
+    t.assign((size_t)N_PAIRS * 512, Z);
+    auto code = [](int tensor, int row, int col, int ncols) { return ((uint32_t)tensor << 24) | (uint32_t)(row * ncols + col); };
+    for (int l = 0; l < NL; ++l)
+        for (int s = 0; s < KS[l]; ++s)
+            for (int nt = 0; nt < NO[l]; ++nt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int j = 0; j < 8; ++j) {
+                        const int h = lane >> 5, i = lane & 31, col = 32 * nt + i, row = hid_feature(s, h, j);
+                        uint32_t c = Z;
+                        switch (l) {
+                            case 0: if (s == 0 && h == 0 && j < 3) c = code(12, j, col, 128); break;      // slots 0..2 carry d r, d g, d b
+                            case 1: if (row < 128) c = code(8, row, col, 280); break;
+                            case 2:                                                                      // k-step 16, slot (0, 0): d sigma
+                                if (s < 16) c = code(14, row, col, 256);
+                                else if (s == 16 && h == 0 && j == 0) c = code(10, 0, col, 256);
+                                break;
+                            case 3: c = code(6, row, col, 256); break;
+                            case 4: c = code(4, row, col, 256); break;
+                            case 5: c = code(2, row, col, 256); break;
+                        }
+                        t[((size_t)(pair_off(l) + s * NO[l] + nt)) * 512 + lane * 8 + j] = c;
+                    }
+}
+
+__global__ void __launch_bounds__(256) k_lcode_pack_bf16_t(NfLcodePtrsBT ptrs, const uint32_t* __restrict__ table,
+                                                           __bf16* __restrict__ stream, int n_entries) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+        const uint32_t code = table[e], id = code >> 24;
+        const float w = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 lo = (__bf16)(w - (float)hi);
+        const int pair = e >> 9, within = e & 511;
+        stream[(size_t)(2 * pair) * 512 + within] = hi;
+        stream[(size_t)(2 * pair + 1) * 512 + within] = lo;
+    }
+}
+
+static std::mutex g_lcode_bt_mutex;
+static uint32_t* g_lcode_bt_table[64] = {nullptr};
+
+extern "C" size_t nf_lcode_packed_bwd_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }
+
+extern "C" int nf_lcode_pack_bwd_bf16(const float* const* params, void* stream_out, nf_stream_t stream) {
+    if (!params || !stream_out) return NF_EINVAL;
+    NfLcodePtrsBT ptrs;
+    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    if (dev < 0 || dev >= 64) return NF_EINVAL;
+    {
+        std::lock_guard<std::mutex> lock(g_lcode_bt_mutex);
+        if (!g_lcode_bt_table[dev]) {
+            std::vector<uint32_t> host;
+            nf_lcode_table_bf16_t(host);
+            uint32_t* d = nullptr;
+            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
+            g_lcode_bt_table[dev] = d;
+        }
+    }
+    hipLaunchKernelGGL(k_lcode_pack_bf16_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_bt_table[dev],
+                       reinterpret_cast<__bf16*>(stream_out), nfb::N_PAIRS * 512);
+    NF_RETURN_LAUNCH();
+}
+
+// =================================================================================================
+// B1 kernel
+// =================================================================================================
+// acc[nt] reg r keeps its value where bit (16 nt + r) of the lane's 128-bit mask is set
+template <int NO>
+__device__ __forceinline__ void nfb_lc_apply_mask(f32x16 (&acc)[8], const u32x4& m) {
+#pragma unroll
+    for (int nt = 0; nt < NO; ++nt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const unsigned bit = (m[nt >> 1] >> (16 * (nt & 1) + r)) & 1u;
+            acc[nt][r] = bit ? acc[nt][r] : 0.0f;
+        }
+}
+
+template <int NO>
+__device__ __forceinline__ void nfb_zero_tiles(f32x16 (&acc)[8]) {
+#pragma unroll
+    for (int nt = 0; nt < NO; ++nt) nfb_zero(acc[nt]);
+}
+
+__global__ void __launch_bounds__(256, 1)
+k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __restrict__ saved, const float* __restrict__ d_raw,
+                           int64_t n_points, float* __restrict__ dz) {
+    using namespace nlc;
+    __shared__ __attribute__((aligned(16))) char lds[NFB_LDS_BYTES];
+    NfbCtx cx;
+    cx.lane = threadIdx.x & 63;
+    cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    cx.lds = lds;
+    cx.gsrc = wstream + cx.lane * 16;
+    const int h = cx.lane >> 5, c = cx.lane & 31;
+    const int64_t p_raw = ((int64_t)blockIdx.x * 4 + cx.wave) * 32 + c;
+    const int64_t p = p_raw < n_points ? p_raw : n_points - 1;
+    const bool live = p_raw < n_points;
+    const int64_t n = n_points;
+
+    // ordinary loads first (d_raw, the five ReLU bit masks), then the ring
+    const f32x4 d = reinterpret_cast<const f32x4*>(d_raw)[p];
+    u32x4 mask[5];
+    const u32x4* mbase = reinterpret_cast<const u32x4*>(saved + (int64_t)S_MASK * n);
+#pragma unroll
+    for (int l = 0; l < 5; ++l) mask[l] = mbase[((int64_t)l * n + p) * 2 + h];
+    nfb_issue<nfb::stage_nblk(0)>(cx, cx.gsrc, nfb::stage_blk0(0), 0);
+    nfb_issue<nfb::stage_nblk(1)>(cx, cx.gsrc, nfb::stage_blk0(1), NFB_STAGE_BYTES);
+    nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
+
+    bf16x8 bh[20], bl[20], th[20], tl[20];
+    {
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && live) { x[0] = d.x; x[1] = d.y; x[2] = d.z; }
+        nfb_split(x, th[0], tl[0]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { th[1][j] = (__bf16)0.f; tl[1][j] = (__bf16)0.f; }
+    }
+    bf16x8 sh, sl;                                                     // d sigma k-step
+    {
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && live) x[0] = d.w;
+        nfb_split(x, sh, sl);
+    }
+    nfb_wait_vm<nfb::inflight_after(-1)>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    f32x16 acc[8];
+#define NFB_LC_BWD_FINISH(NO_, MASK_, ZSEC_)                                                             \
+    do {                                                                                                 \
+        if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                 \
+        if (live) nfb_save_tiles<NO_>(acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p, h);                 \
+        nfb_to_operands<NO_, false>(acc, bh, bl, 0);                                                     \
+    } while (0)
+    // mask indices: layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
+    nfb_zero_tiles<4>(acc);
+    NFB_LAYER(0, acc, th, tl);
+    NFB_LC_BWD_FINISH(4, 4, Z_DIR);
+    nfb_zero_tiles<8>(acc);
+    NFB_LAYER(1, acc, bh, bl);
+    NFB_LC_BWD_FINISH(8, 3, Z_FEAT);
+    // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight (fc_alpha reads x), gated by layers_xyz.2's ReLU
+#pragma unroll
+    for (int s = 0; s < 16; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
+    th[16] = sh; tl[16] = sl;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { th[17][j] = (__bf16)0.f; tl[17][j] = (__bf16)0.f; }
+    nfb_zero_tiles<8>(acc);
+    NFB_LAYER(2, acc, th, tl);
+    NFB_LC_BWD_FINISH(8, 2, Z_X2);
+    nfb_zero_tiles<8>(acc);
+    NFB_LAYER(3, acc, bh, bl);
+    NFB_LC_BWD_FINISH(8, 1, Z_X1);
+    nfb_zero_tiles<8>(acc);
+    NFB_LAYER(4, acc, bh, bl);
+    NFB_LC_BWD_FINISH(8, 0, Z_X0);
+    nfb_zero_tiles<8>(acc);
+    NFB_LAYER(5, acc, bh, bl);                                         // layer1 has no activation: dZ = d(out)
+    if (live) nfb_save_tiles<8>(acc, dz + (int64_t)Z_L1 * n, 256, p, h);
+#undef NFB_LC_BWD_FINISH
+}
+
+int nfb_lcode_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                               nf_stream_t stream) {
+    const int64_t grid = (n_points + 127) / 128;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_lcode_mlp_bwd_chain_bf16, dim3((unsigned)grid), dim3(256), 0, nf_s(stream),
+                       reinterpret_cast<const char*>(packed_t_bf16), saved, d_raw, n_points, dz);
+    NF_RETURN_LAUNCH();
+}

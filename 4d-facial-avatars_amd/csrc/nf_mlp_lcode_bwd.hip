@@ -251,27 +251,39 @@ static const int NF_LC_PARAM_NUMEL[nlc::NPARAMS] = {256 * 171, 256, 65536, 256, 
 
 extern "C" size_t nf_lcode_grad_floats(void) { return (size_t)nlc::GRAD_FLOATS; }
 
+// defined in nf_mlp_bf16_dw.hip / nf_mlp_lcode_bf16_bwd.hip
+void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices);
+int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                       int n_slices, float* slabs, nf_stream_t stream);
+int nfb_lcode_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                               nf_stream_t stream);
+
 extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
-    int64_t pps; int ns;
+    int64_t pps; int ns, ns_b;
     nf_bwd_plan(n_points, &pps, &ns);
+    nfb_dw_plan(1, n_points, &pps, &ns_b);
+    if (ns_b > ns) ns = ns_b;
     return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS;
 }
 
 static NfDwJobTable g_lcode_jobs;
 
 // grads: nf_lcode_grad_floats() floats = the 16 tensors in nerf.models.LCODE_KEYS order, flattened, then d latent (32)
-extern "C" int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved, const float* d_raw,
-                                int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
-                                nf_stream_t stream) {
+static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const float* cond, const float* saved,
+                             const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
+                             nf_stream_t stream) {
     using namespace nlc;
-    if (!packed || !packed_t || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0) return NF_EINVAL;
+    if (!packed || (!packed_t && !packed_t_bf16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0)
+        return NF_EINVAL;
+    const bool split = packed_t_bf16 != nullptr;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_lcode_bwd_workspace_floats(n_points)) return NF_EINVAL;
     const NfDwJob* jobs = nullptr;
     const int rcj = g_lcode_jobs.get(NF_LC_DW_JOBS, nf_lcode_build_dw_jobs, &jobs);
     if (rcj) return rcj;
     int64_t pps; int ns;
-    nf_bwd_plan(n_points, &pps, &ns);
+    if (split) nfb_dw_plan(1, n_points, &pps, &ns);
+    else nf_bwd_plan(n_points, &pps, &ns);
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
@@ -282,13 +294,37 @@ extern "C" int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, cons
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_lcode_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);
-    hipLaunchKernelGGL((k_dw_gemm<1>), dim3((NF_LC_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_LC_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
-                       saved, n_points, pps, slabs);
+    if (split) {
+        int rc = nfb_lcode_launch_bwd_chain(packed_t_bf16, saved, d_raw, n_points, dz, stream);
+        if (rc) return rc;
+        rc = nfb_launch_dw_gemm(1, dz, d_raw, saved, n_points, pps, ns, slabs, stream);
+        if (rc) return rc;
+    } else {
+        hipLaunchKernelGGL((k_lcode_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);
+        hipLaunchKernelGGL((k_dw_gemm<1>), dim3((NF_LC_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_LC_DW_JOBS, (int)SLAB_FLOATS, dz,
+                           d_raw, saved, n_points, pps, slabs);
+    }
     hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
     NfLcodeGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NPARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_LC_PARAM_NUMEL[i];
     hipLaunchKernelGGL(k_lcode_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved, const float* d_raw,
+                                int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
+                                nf_stream_t stream) {
+    if (!packed_t) return NF_EINVAL;
+    return nf_lcode_bwd_impl(packed, packed_t, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+}
+
+// Same on the split-bf16 kernels (dX chain nf_mlp_lcode_bf16_bwd.hip, weight-gradient GEMMs nf_mlp_bf16_dw.hip); `saved` must come
+// from nf_lcode_mlp_fwd_train_bf16 (it carries the ReLU bit masks the chain reads).
+extern "C" int nf_lcode_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
+                                     const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                     float* grads, nf_stream_t stream) {
+    if (!packed_t_bf16) return NF_EINVAL;
+    return nf_lcode_bwd_impl(packed, nullptr, packed_t_bf16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads,
+                             stream);
 }

@@ -30,7 +30,9 @@ constexpr int S_X0 = 320, S_X1 = 576, S_X2 = 832;         // 256 each, post-ReLU
 constexpr int S_FEAT = 1088;                              // 256, relu(fc_feat)
 constexpr int S_DIR = 1344;                               // 128, relu(layers_dir.0)
 constexpr int S_DIRF = 1472;                              // 16, dir slot order (sin, cos, 0, 0)(rd_z 2^g)
-constexpr int SAVED_PER_POINT = 1488;
+constexpr int S_MASK = 1488;                              // split-bf16 training forward only: ReLU bit masks of layers_xyz.0..2, fc_feat,
+                                                          // layers_dir.0 x [n points] x [2 lane halves] x 4 dwords (as nfl::S_MASK)
+constexpr int SAVED_PER_POINT = 1488 + 5 * 8;
 // ---- pre-activation gradients written by the backward chain ------------------------------------------------------
 constexpr int Z_L1 = 0, Z_X0 = 256, Z_X1 = 512, Z_X2 = 768, Z_FEAT = 1024, Z_DIR = 1280;
 constexpr int DZ_PER_POINT = 1408;

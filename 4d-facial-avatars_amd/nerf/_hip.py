@@ -55,6 +55,10 @@ _PROTOTYPES = {
     "nf_lcode_packed_bf16_bytes": (_Z, []),
     "nf_lcode_pack_bf16": (C.c_int, [_P, _P, _P]),
     "nf_lcode_mlp_fwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_lcode_mlp_fwd_train_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "nf_lcode_packed_bwd_bf16_bytes": (_Z, []),
+    "nf_lcode_pack_bwd_bf16": (C.c_int, [_P, _P, _P]),
+    "nf_lcode_mlp_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_lcode_saved_floats": (_Z, [_L]),
     "nf_lcode_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_floats": (_Z, []),

@@ -159,6 +159,8 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         self._sig_t = None
         self._packed_b = None
         self._sig_b = None
+        self._packed_bt = None
+        self._sig_bt = None
 
     def fused_supported(self) -> bool:
         return (self.use_viewdirs and self.dim_xyz == 63 and self.dim_dir == 24 and self.dim_expression == 76
@@ -199,6 +201,21 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             self._sig_b = sig
         return self._packed_b
 
+    def _hip_packed_bf16_t(self):
+        import ctypes as C
+        from . import _hip as H
+        ps = self.hip_param_list()
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        if self._packed_bt is None or sig != self._sig_bt:
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            self._packed_bt = torch.empty(lib.nf_lcode_packed_bwd_bf16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_lcode_pack_bwd_bf16(arr, H.ptr(self._packed_bt), H.stream_ptr(dev)), "nf_lcode_pack_bwd_bf16")
+            self._sig_bt = sig
+        return self._packed_bt
+
     def _hip_packed_t(self):
         import ctypes as C
         from . import _hip as H
@@ -228,33 +245,44 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                                            H.ptr(cond), H.stream_ptr(dev)), "nf_lcode_condition")
             if not need_grad:
                 from . import ops
-                if ops.get_mlp_precision() == "bf16x3":      # split-bf16 inference kernel; training of this family stays exact f32
+                if ops.get_mlp_precision() == "bf16x3":
                     H.check(lib.nf_lcode_mlp_fwd_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
                                                       H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_bf16")
                 else:
                     H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
                                                  n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
                 return raw, None
+            from . import ops
+            split = ops.get_mlp_precision() == "bf16x3"
             saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
-            H.check(lib.nf_lcode_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
-                                               n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_train")
-        return raw, (packed, cond, saved)
+            if split:
+                H.check(lib.nf_lcode_mlp_fwd_train_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
+                                                        H.ptr(z), n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
+                        "nf_lcode_mlp_fwd_train_bf16")
+            else:
+                H.check(lib.nf_lcode_mlp_fwd_train(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
+                                                   n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_train")
+        return raw, (packed, cond, saved, split)
 
     def hip_backward(self, state, z, d_raw):
         """d_raw (n_rays, n_samples, 4) -> ([16 parameter gradients in hip_param_list order], d latent (32))."""
         from . import _hip as H
-        packed, cond, saved = state
+        packed, cond, saved, split = state
         lib = H.lib()
         d_raw = d_raw.contiguous()
         dev = H.require_device(packed, cond, saved, d_raw)
         n_rays, n_samples = z.shape
-        packed_t = self._hip_packed_t()
         ws_floats = lib.nf_lcode_bwd_workspace_floats(n_rays * n_samples)
         ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         flat = torch.empty(lib.nf_lcode_grad_floats(), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            H.check(lib.nf_lcode_mlp_bwd(H.ptr(packed), H.ptr(packed_t), H.ptr(cond), H.ptr(saved), H.ptr(d_raw), n_rays, n_samples,
-                                         H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_lcode_mlp_bwd")
+            if split:     # forward was the split-bf16 training forward (bit masks present): split-bf16 chain + dW GEMMs
+                H.check(lib.nf_lcode_mlp_bwd_bf16(H.ptr(packed), H.ptr(self._hip_packed_bf16_t()), H.ptr(cond), H.ptr(saved), H.ptr(d_raw),
+                                                  n_rays, n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)),
+                        "nf_lcode_mlp_bwd_bf16")
+            else:
+                H.check(lib.nf_lcode_mlp_bwd(H.ptr(packed), H.ptr(self._hip_packed_t()), H.ptr(cond), H.ptr(saved), H.ptr(d_raw), n_rays,
+                                             n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_lcode_mlp_bwd")
         grads, off = [], 0
         for p in self.hip_param_list():
             n = p.numel()

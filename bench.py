@@ -137,6 +137,7 @@ TRAIN_BYTES_PER_POINT = {
     ("paper", "bf16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
     ("paper", "f32"): 4 * 2256 + (4 * (6 * 256 + 3 * 128) + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
     ("lcode", "f32"): 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+    ("lcode", "bf16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
 }
 
 
@@ -166,7 +167,7 @@ def train_roofline(args, model, dev, n_rays):
         torch.cuda.synchronize()
         total_ms += e0.elapsed_time(e1) / reps
         total_pts += n_rays * s
-    prec = args.precision if args.family == "paper" else "f32"
+    prec = args.precision
     bpp = TRAIN_BYTES_PER_POINT[(args.family, prec)]
     achieved = bpp * total_pts / (total_ms * 1e-3) / 1e9
     return {"bound": "hbm", "kernel": f"{args.family} MLP training kernels of ONE model per iteration (training forward + dX chain + dW GEMMs "
@@ -249,12 +250,12 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if (args.precision == "bf16x3" and args.family == "paper") else "f32",
+            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32",
             "data": "synthetic",
             "config": {"workload": f"configs[2]: {args.family}-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
                                    "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
                        "rays_per_step": n_rays * world, "parallelism": f"dp{world}",
-                       "mlp_precision": args.precision if args.family == "paper" else "f32", "family": args.family}}), flush=True)
+                       "mlp_precision": args.precision, "family": args.family}}), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -271,7 +272,7 @@ def main():
                          "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
     ap.add_argument("--chunksize", type=int, default=CHUNK, help="validation ray chunk (shipped configs: 65536)")
     ap.add_argument("--family", choices=["paper", "lcode"], default="paper",
-                    help="train mode only: lcode = ConditionalBlendshapeLearnableCodeNeRFModel (exact-f32 kernels)")
+                    help="train mode only: lcode = ConditionalBlendshapeLearnableCodeNeRFModel")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=12288)

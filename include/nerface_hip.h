@@ -162,6 +162,16 @@ int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, const float* co
                      int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
                      nf_stream_t stream);
 
+/* Training of the same family on the split-bf16 kernels (forward, dX chain, weight-gradient GEMMs; reductions f32).   */
+int nf_lcode_mlp_fwd_train_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
+                                const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
+                                float* saved, nf_stream_t stream);
+size_t nf_lcode_packed_bwd_bf16_bytes(void);
+int nf_lcode_pack_bwd_bf16(const float* const* params, void* packed_t_bf16, nf_stream_t stream);
+int nf_lcode_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
+                          const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                          float* grads, nf_stream_t stream);
+
 /* ---- BASELINE config 1: tiny_nerf.py (reference tiny_nerf.py:12-181) ----------------------------------------------
  * nf_tiny_mlp_fwd = compute_query_points_from_rays' pts = ro + rd*depth (tiny_nerf.py:59-63) + positional_encoding(., 10)
  * + VeryTinyNerfModel.forward (63 -> 128 -> 128 -> 4).  params: HOST array of 6 device pointers
