@@ -365,7 +365,8 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
     }
 }
 
-static std::once_flag g_dwb_once[64];
+static std::mutex g_dwb_mutex;
+static bool g_dwb_ready[64] = {false};
 
 // called by nf_paper_mlp_bwd_bf16 (nf_mlp_bwd.hip) / nf_lcode_mlp_bwd_bf16; slabs: n_slices x slab floats of the model
 int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
@@ -374,16 +375,18 @@ int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const flo
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= 64) return NF_EINVAL;
-    int rc = 0;
-    std::call_once(g_dwb_once[dev], [&]() {
-        static NfbDwJob jobs[NFB_DW_JOBS], jobs_l[NFB_DW_JOBS_LCODE];
-        nfb_build_dw_jobs(jobs);
-        nfb_build_dw_jobs_lcode(jobs_l);
-        hipError_t ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs), jobs, sizeof(jobs));
-        if (ee == hipSuccess) ee = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs_lcode), jobs_l, sizeof(jobs_l));
-        if (ee != hipSuccess) rc = (int)ee;
-    });
-    if (rc) return rc;
+    {
+        std::lock_guard<std::mutex> lock(g_dwb_mutex);
+        if (!g_dwb_ready[dev]) {                      // job tables -> constant memory of this device (marked ready only on success)
+            static NfbDwJob jobs[NFB_DW_JOBS], jobs_l[NFB_DW_JOBS_LCODE];
+            nfb_build_dw_jobs(jobs);
+            nfb_build_dw_jobs_lcode(jobs_l);
+            e = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs), jobs, sizeof(jobs));
+            if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(c_dwb_jobs_lcode), jobs_l, sizeof(jobs_l));
+            if (e != hipSuccess) return (int)e;
+            g_dwb_ready[dev] = true;
+        }
+    }
     if (model == 0)
         hipLaunchKernelGGL((k_paper_dw_gemm_bf16<0>), dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream), dz,
                            d_raw, saved, n_points, pts_per_slice, slabs, (int)nfl::SLAB_FLOATS);

@@ -115,13 +115,23 @@ k_dw_gemm(const NfDwJob* __restrict__ jobs, int n_jobs, int slab_floats, const f
 }
 
 
-// B3, first half: sum the per-slice slabs in a fixed order (deterministic)
+// B3, first half: sum the per-slice slabs in a fixed order (deterministic).  16 bytes per thread, four independent partial
+// sums (slices k = 0, 1, 2, 3 mod 4) so that the loads of consecutive slices overlap; slab_floats is a multiple of 4.
 template <int MODEL>
 __global__ void __launch_bounds__(256) k_grad_reduce(const float* __restrict__ slabs, int n_slices, int slab_floats, float* __restrict__ sum) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < slab_floats; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < n_slices; ++k) s += slabs[(int64_t)k * slab_floats + e];
-        sum[e] = s;
+    const int n4 = slab_floats >> 2;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + e;
+        f32x4 a[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) a[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= n_slices; k += 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) a[q] += src[(int64_t)(k + q) * n4];
+        }
+        for (; k < n_slices; ++k) a[k & 3] += src[(int64_t)k * n4];
+        reinterpret_cast<f32x4*>(sum)[e] = (a[0] + a[1]) + (a[2] + a[3]);
     }
 }
 
