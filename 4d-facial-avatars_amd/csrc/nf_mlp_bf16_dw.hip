@@ -19,6 +19,7 @@
 //               in f32,
 //       M(i-1)  2 + 2 fragment pairs per wave (conflict-free ds_read_b128), 12 MFMAs, branch-free.
 #include <mutex>
+#include <vector>
 
 #include "nf_mlp_bf16_common.h"
 #include "nf_mlp_lcode_layout.h"
@@ -46,7 +47,7 @@ struct NfbDwJob {
     NfbDwProd prod[NFB_DW_WAVES];
 };
 
-#define NFB_DW_JOBS 12                                   // paper model
+#define NFB_DW_JOBS 11                                   // paper model
 #define NFB_DW_JOBS_LCODE 8                              // second model family
 #define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
 #define NFB_DW_NSET 3                                    // register sets of raw tiles: 2 stages of loads in flight
@@ -396,13 +397,65 @@ int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const flo
     NF_RETURN_LAUNCH();
 }
 
-// slices for the split-bf16 dW kernel: about 504 workgroups = two rounds of the 256 CUs (paper: 12 bundles x 42 slices,
+// slices for the split-bf16 dW kernel: about 504 workgroups = two rounds of the 256 CUs (paper: 11 bundles x 46 slices,
 // second family: 8 bundles x 63 slices)
 void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
-    const int target = model == 0 ? 42 : 63;
+    const int target = model == 0 ? 46 : 63;
     int64_t pps = (n_points + target - 1) / target;
     pps = (pps + 15) / 16 * 16;
     if (pps < 256) pps = 256;
     *pts_per_slice = pps;
     *n_slices = (int)((n_points + pps - 1) / pps);
+}
+
+// =================================================================================================
+// host-only self-test of the job tables (no device needed; tests/test_host.py): every slab entry the unpack kernels read
+// must be written by exactly one (bundle, wave) per slice, nothing may be written twice, and every wave's tile ids must
+// stay inside its bundle.  Returns 0, or a negative code that says what failed.
+// =================================================================================================
+static int nfb_check_tables(const NfbDwJob* jobs, int n_jobs, int slab_floats, long expected_entries) {
+    std::vector<unsigned char> hits((size_t)slab_floats, 0);
+    long total = 0;
+    for (int jb = 0; jb < n_jobs; ++jb) {
+        const NfbDwJob& j = jobs[jb];
+        if (j.nseg < 1 || j.nseg > 4 || j.ntile < 1 || j.ntile > NFB_DW_MAX_TILES) return -1;
+        for (int t = 0; t < j.ntile; ++t) {
+            const NfbDwTile& tl = j.tile[t];
+            if (tl.seg < 0 || tl.seg >= j.nseg || tl.f0 < 0 || tl.f0 >= j.seg[tl.seg].width) return -2;
+            if (tl.cs_off >= 0)
+                for (int c = 0; c < 32 && tl.f0 + c < j.seg[tl.seg].width; ++c) {
+                    if (tl.cs_off + c >= slab_floats) return -3;
+                    if (hits[tl.cs_off + c]++) return -4;
+                    ++total;
+                }
+        }
+        for (int w = 0; w < NFB_DW_WAVES; ++w) {
+            const NfbDwProd& p = j.prod[w];
+            if (p.a_tile < 0 || p.b_tile < 0 || p.a_tile + 2 > NFB_DW_MAX_TILES || p.b_tile + 2 > NFB_DW_MAX_TILES) return -5;
+            if (p.a_valid > 0 && (p.a_tile + p.na > j.ntile || p.b_tile + p.nb > j.ntile || p.na > 2 || p.nb > 2)) return -6;
+            for (int r = 0; r < p.a_valid; ++r)
+                for (int c = 0; c < p.b_valid; ++c) {
+                    const long e = (long)p.out_off + (long)r * p.ldo + c;
+                    if (e < 0 || e >= slab_floats) return -7;
+                    if (hits[e]++) return -8;
+                    ++total;
+                }
+        }
+    }
+    return total == expected_entries ? 0 : -9;
+}
+
+extern "C" int nf_selftest_dw_tables_bf16(void) {
+    static NfbDwJob jobs[NFB_DW_JOBS], jobs_l[NFB_DW_JOBS_LCODE];
+    nfb_build_dw_jobs(jobs);
+    nfb_build_dw_jobs_lcode(jobs_l);
+    // paper: dW of layers_xyz.0 / .3 (PE part) 2 x 256 x 64, six 256 x 256, layers_dir.0 128 x (256 + 16), two 128 x 128,
+    // fc_rgb / fc_alpha as 4 rows of d_raw each, column sums 7 x 256 + 3 x 128 + 4
+    const long paper = 2L * 256 * 64 + 6L * 65536 + 128L * 272 + 2L * 128 * 128 + 4L * 128 + 4L * 256 + 7 * 256 + 3 * 128 + 4;
+    int rc = nfb_check_tables(jobs, NFB_DW_JOBS, nfl::SLAB_FLOATS, paper);
+    if (rc) return rc;
+    // second family: layer1 (PE part) 256 x 64, four 256 x 256, layers_dir.0 128 x (256 + 16), 4 x 128, 4 x 256, sums 5 x 256 + 128 + 4
+    const long lcode = 256L * 64 + 4L * 65536 + 128L * 272 + 4L * 128 + 4L * 256 + 5 * 256 + 128 + 4;
+    rc = nfb_check_tables(jobs_l, NFB_DW_JOBS_LCODE, nlc::SLAB_FLOATS, lcode);
+    return rc ? rc - 100 : 0;
 }

@@ -399,3 +399,11 @@ extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_b
     return nf_bwd_impl(packed, nullptr, packed_t_bf16, exact_dw == 0, cond, saved, d_raw, n_rays, n_samples, workspace,
                        workspace_floats, grads, stream);
 }
+
+// host-only self-test of the exact-f32 job table (tests/test_host.py)
+extern "C" int nf_selftest_dw_tables_f32(void) {
+    NfDwJob jobs[NF_DW_JOBS];
+    nf_build_dw_jobs(jobs);
+    const long paper = 2L * 256 * 64 + 6L * 65536 + 128L * 272 + 2L * 128 * 128 + 4L * 128 + 4L * 256 + 7 * 256 + 3 * 128 + 4;
+    return nf_check_dw_jobs(jobs, NF_DW_JOBS, nfl::SLAB_FLOATS, paper);
+}

@@ -169,3 +169,27 @@ struct NfDwJobTable {
         return 0;
     }
 };
+
+// host-only self-test of an exact-f32 job table: no slab entry written twice, `expected_entries` entries written in total
+static inline int nf_check_dw_jobs(const NfDwJob* jobs, int n_jobs, int slab_floats, long expected_entries) {
+    std::vector<unsigned char> hits((size_t)slab_floats, 0);
+    long total = 0;
+    for (int jb = 0; jb < n_jobs; ++jb) {
+        const NfDwJob& j = jobs[jb];
+        if (j.n_valid < 1 || j.n_valid > 128 || j.k_valid < 1 || j.k_valid > 128) return -1;
+        for (int r = 0; r < j.n_valid; ++r)
+            for (int c = 0; c < j.k_valid; ++c) {
+                const long e = (long)j.out_off + (long)r * j.ldo + c;
+                if (e < 0 || e >= slab_floats) return -2;
+                if (hits[e]++) return -3;
+                ++total;
+            }
+        if (j.cs_off >= 0)
+            for (int r = 0; r < j.n_valid; ++r) {
+                if (j.cs_off + r >= slab_floats) return -4;
+                if (hits[j.cs_off + r]++) return -5;
+                ++total;
+            }
+    }
+    return total == expected_entries ? 0 : -6;
+}

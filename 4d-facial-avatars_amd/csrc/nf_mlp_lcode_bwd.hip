@@ -328,3 +328,11 @@ extern "C" int nf_lcode_mlp_bwd_bf16(const float* packed, const void* packed_t_b
     return nf_lcode_bwd_impl(packed, nullptr, packed_t_bf16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads,
                              stream);
 }
+
+// host-only self-test of this family's exact-f32 job table (tests/test_host.py)
+extern "C" int nf_selftest_dw_tables_lcode_f32(void) {
+    NfDwJob jobs[NF_LC_DW_JOBS];
+    nf_lcode_build_dw_jobs(jobs);
+    const long lcode = 256L * 64 + 4L * 65536 + 128L * 272 + 4L * 128 + 4L * 256 + 5 * 256 + 128 + 4;
+    return nf_check_dw_jobs(jobs, NF_LC_DW_JOBS, nlc::SLAB_FLOATS, lcode);
+}

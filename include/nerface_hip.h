@@ -220,6 +220,12 @@ int nf_render_rays_fwd(const float* packed_coarse, const void* packed_bf16_coars
 /* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
 int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);
 
+/* ---- host-only self-tests (no device needed): consistency of the weight-gradient job tables -- every slab entry written
+ * exactly once per slice, tile ids inside their bundle.  0 = consistent, negative = which check failed.                 */
+int nf_selftest_dw_tables_f32(void);
+int nf_selftest_dw_tables_lcode_f32(void);
+int nf_selftest_dw_tables_bf16(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,14 @@ def test_gather_table_covers_every_live_weight_once(hip_lib):
     assert np.all(cnt0[:, 63:] == 1) and np.all(cnt0[:, :63] == 0)
 
 
+def test_weight_gradient_job_tables_are_consistent(hip_lib):
+    """Host-only self-tests of the dW job tables (exact-f32 wave jobs and split-bf16 workgroup bundles, both model families):
+    every slab entry the unpack kernels read is written exactly once per slice, nothing twice, tile ids inside their bundle."""
+    assert hip_lib.nf_selftest_dw_tables_f32() == 0
+    assert hip_lib.nf_selftest_dw_tables_lcode_f32() == 0
+    assert hip_lib.nf_selftest_dw_tables_bf16() == 0
+
+
 def test_state_dict_schema_matches_reference_checkpoints():
     import nerf
     m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
