@@ -151,3 +151,14 @@ extern "C" int nf_paper_mlp_fwd_train_bf16(const void* packed_bf16, const float*
     if (!saved) return NF_EINVAL;
     return nfb_launch(packed_bf16, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, saved, stream);
 }
+
+// host-only: the gather table of this stream (one 32-bit code per bf16 element of the hi blocks: tensor id << 24 | element
+// offset, 0xFF000000 = zero) for tests/test_host.py; out == NULL returns the number of entries.  Forward stream of the paper model.
+extern "C" long nf_paper_stream_table_bf16(uint32_t* out, size_t n_entries) {
+    std::vector<uint32_t> t;
+    nf_build_table_bf16(t);
+    if (!out) return (long)t.size();
+    if (n_entries != t.size()) return -1;
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    return (long)t.size();
+}

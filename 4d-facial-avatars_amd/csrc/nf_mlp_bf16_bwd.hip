@@ -229,3 +229,14 @@ int nfb_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const fl
                        reinterpret_cast<const char*>(packed_t_bf16), saved, d_raw, n_points, dz);
     NF_RETURN_LAUNCH();
 }
+
+// host-only: the gather table of this stream (one 32-bit code per bf16 element of the hi blocks: tensor id << 24 | element
+// offset, 0xFF000000 = zero) for tests/test_host.py; out == NULL returns the number of entries.  Transposed (backward-chain) stream of the paper model.
+extern "C" long nf_paper_stream_table_bwd_bf16(uint32_t* out, size_t n_entries) {
+    std::vector<uint32_t> t;
+    nf_build_table_bf16_t(t);
+    if (!out) return (long)t.size();
+    if (n_entries != t.size()) return -1;
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    return (long)t.size();
+}

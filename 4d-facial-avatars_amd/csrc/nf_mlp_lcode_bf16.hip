@@ -104,3 +104,14 @@ extern "C" int nf_lcode_mlp_fwd_bf16(const void* packed_bf16, const float* cond,
                        cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, (float*)nullptr);
     NF_RETURN_LAUNCH();
 }
+
+// host-only: the gather table of this stream (one 32-bit code per bf16 element of the hi blocks: tensor id << 24 | element
+// offset, 0xFF000000 = zero) for tests/test_host.py; out == NULL returns the number of entries.  Forward stream of the second model family.
+extern "C" long nf_lcode_stream_table_bf16(uint32_t* out, size_t n_entries) {
+    std::vector<uint32_t> t;
+    nf_lcode_table_bf16(t);
+    if (!out) return (long)t.size();
+    if (n_entries != t.size()) return -1;
+    for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
+    return (long)t.size();
+}

@@ -62,6 +62,10 @@ _PROTOTYPES = {
     "nf_selftest_dw_tables_f32": (C.c_int, []),
     "nf_selftest_dw_tables_lcode_f32": (C.c_int, []),
     "nf_selftest_dw_tables_bf16": (C.c_int, []),
+    "nf_paper_stream_table_bf16": (C.c_long, [_P, _Z]),
+    "nf_paper_stream_table_bwd_bf16": (C.c_long, [_P, _Z]),
+    "nf_lcode_stream_table_bf16": (C.c_long, [_P, _Z]),
+    "nf_lcode_stream_table_bwd_bf16": (C.c_long, [_P, _Z]),
     "nf_lcode_saved_floats": (_Z, [_L]),
     "nf_lcode_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_floats": (_Z, []),

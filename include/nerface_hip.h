@@ -225,6 +225,12 @@ int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_str
 int nf_selftest_dw_tables_f32(void);
 int nf_selftest_dw_tables_lcode_f32(void);
 int nf_selftest_dw_tables_bf16(void);
+/* gather tables of the four split-bf16 weight streams (host code; out == NULL: number of entries): one code per element of
+ * the hi blocks, tensor id << 24 | element offset, 0xFF000000 = zero padding                                            */
+long nf_paper_stream_table_bf16(uint32_t* out, size_t n_entries);
+long nf_paper_stream_table_bwd_bf16(uint32_t* out, size_t n_entries);
+long nf_lcode_stream_table_bf16(uint32_t* out, size_t n_entries);
+long nf_lcode_stream_table_bwd_bf16(uint32_t* out, size_t n_entries);
 
 #ifdef __cplusplus
 }

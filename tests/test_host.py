@@ -72,6 +72,58 @@ def test_weight_gradient_job_tables_are_consistent(hip_lib):
     assert hip_lib.nf_selftest_dw_tables_bf16() == 0
 
 
+def _stream_table(hip_lib, fn):
+    n = getattr(hip_lib, fn)(None, 0)
+    assert n > 0
+    tab = np.zeros(n, dtype=np.uint32)
+    assert getattr(hip_lib, fn)(tab.ctypes.data_as(ctypes.c_void_p), n) == n
+    return tab >> 24, tab & 0xFFFFFF
+
+
+def _check_stream(ids, offs, shapes, expect):
+    """expect: tensor id -> boolean array (tensor shape): which elements must appear exactly once; all others never."""
+    for tid, shp in enumerate(shapes):
+        cnt = np.bincount(offs[ids == tid], minlength=int(np.prod(shp))).reshape(shp)
+        want = expect.get(tid)
+        if want is None:
+            assert cnt.sum() == 0, tid
+        else:
+            assert np.array_equal(cnt, want.astype(cnt.dtype)), (tid, int((cnt != want).sum()))
+    assert set(np.unique(ids)) <= set(expect) | {0xFF}
+
+
+def test_split_bf16_weight_streams_cover_the_right_elements_once(hip_lib):
+    """Gather tables of the four split-bf16 weight streams: every weight element the kernels multiply by appears exactly once,
+    the folded columns (expression, latent, PE of near/far: they live in the per-call bias table) and the biases never, the
+    dead layers_dir.3 never; the transposed streams hold exactly the weights the dX chain needs."""
+    import nerf
+    full = lambda shp: np.ones(shp, dtype=bool)
+    cols = lambda shp, sel: np.broadcast_to(np.isin(np.arange(shp[1]), list(sel)), shp)
+    dir_live = list(range(256)) + [256 + 6 * f + 3 * sc for f in range(4) for sc in range(2)]       # feat + sin/cos of rd_z
+    # ---- paper model (ids = position in ops.PAPER_KEYS: weight 2 i, bias 2 i + 1)
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False)
+    shapes = [tuple(p.shape) if p.dim() == 2 else (1, p.numel()) for p in m.hip_param_list()]
+    fwd = {0: cols(shapes[0], range(63)), 2: full(shapes[2]), 4: full(shapes[4]),
+           6: cols(shapes[6], list(range(63)) + list(range(171, 427))), 8: full(shapes[8]), 10: full(shapes[10]), 12: full(shapes[12]),
+           14: full(shapes[14]), 16: cols(shapes[16], dir_live), 18: full(shapes[18]), 20: full(shapes[20]), 24: full(shapes[24])}
+    _check_stream(*_stream_table(hip_lib, "nf_paper_stream_table_bf16"), shapes, fwd)
+    bwd = {24: full(shapes[24]), 20: full(shapes[20]), 18: full(shapes[18]), 16: cols(shapes[16], range(256)), 14: full(shapes[14]),
+           12: full(shapes[12]), 10: full(shapes[10]), 8: full(shapes[8]), 6: cols(shapes[6], range(171, 427)), 4: full(shapes[4]),
+           2: full(shapes[2])}                                          # layers_xyz.0 feeds no dX
+    _check_stream(*_stream_table(hip_lib, "nf_paper_stream_table_bwd_bf16"), shapes, bwd)
+    # ---- second family (ids = position in models.LCODE_KEYS)
+    ml = nerf.models.ConditionalBlendshapeLearnableCodeNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                                 include_input_dir=False, num_layers=4, hidden_size=256)
+    shp = [tuple(p.shape) if p.dim() == 2 else (1, p.numel()) for p in ml.hip_param_list()]
+    fwd = {0: cols(shp[0], range(63)), 2: full(shp[2]), 4: full(shp[4]), 6: full(shp[6]), 8: cols(shp[8], dir_live), 10: full(shp[10]),
+           12: full(shp[12]), 14: full(shp[14])}
+    _check_stream(*_stream_table(hip_lib, "nf_lcode_stream_table_bf16"), shp, fwd)
+    bwd = {12: full(shp[12]), 8: cols(shp[8], range(256)), 14: full(shp[14]), 10: full(shp[10]), 6: full(shp[6]), 4: full(shp[4]),
+           2: full(shp[2])}                                             # layer1 feeds no dX
+    _check_stream(*_stream_table(hip_lib, "nf_lcode_stream_table_bwd_bf16"), shp, bwd)
+
+
 def test_state_dict_schema_matches_reference_checkpoints():
     import nerf
     m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
