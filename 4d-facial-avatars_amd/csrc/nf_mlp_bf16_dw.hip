@@ -50,7 +50,7 @@ struct NfbDwJob {
 #define NFB_DW_JOBS 11                                   // paper model
 #define NFB_DW_JOBS_LCODE 8                              // second model family
 #define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
-#define NFB_DW_NSET 3                                    // register sets of raw tiles: 2 stages of loads in flight
+#define NFB_DW_NSET 3                                    // register sets of raw tiles: NSET - 1 stages of loads in flight
 #define NFB_DW_CVT_U4 (NFB_DW_MAX_TILES * 128)           // 16-byte units: per tile 64 lanes x (hi, lo)
 __constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
 __constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
@@ -305,7 +305,7 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) al[t] = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
-        load(i + 2, xn);
+        load(i + NFB_DW_NSET - 1, xn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -316,12 +316,12 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
 
     // the first M step (i = 0) reads fragment buffer 1 before anything was converted into it
     for (int e = threadIdx.x; e < NFB_DW_CVT_U4; e += 64 * NFB_DW_WAVES) lds_cvt[NFB_DW_CVT_U4 + e] = make_uint4(0u, 0u, 0u, 0u);
-    load(0, xs[0]);
-    load(1, xs[1]);
+#pragma unroll
+    for (int q = 0; q < NFB_DW_NSET - 1; ++q) load(q, xs[q]);
     __syncthreads();
     for (int i0 = 0; i0 <= n_stages; i0 += NFB_DW_NSET) {
 #pragma unroll
-        for (int q = 0; q < NFB_DW_NSET; ++q) stage(i0 + q, xs[q], xs[(q + 2) % NFB_DW_NSET]);
+        for (int q = 0; q < NFB_DW_NSET; ++q) stage(i0 + q, xs[q], xs[(q + NFB_DW_NSET - 1) % NFB_DW_NSET]);
     }
     if (n_tail > 0) {   // the partial stage (last slice only), not pipelined
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
