@@ -18,11 +18,11 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_pack.h"
 
 // =================================================================================================
 // pack: gather the 26 nn.Parameter storages into the fragment-ordered image
 // =================================================================================================
-struct NfParamPtrs { const float* p[NF_PAPER_NUM_PARAMS]; };
 
 static const uint32_t NF_ZERO_CODE = 0xFF000000u;
 static inline uint32_t nf_code(int tensor, int row, int col, int ncols) { return ((uint32_t)tensor << 24) | (uint32_t)(row * ncols + col); }
@@ -98,38 +98,7 @@ static void nf_build_gather_table(std::vector<uint32_t>& t) {
     for (int n = 0; n < 3; ++n) t[OFF_BIAS + B_RGB + n] = nf_code(ID_RGB_B, 0, n, 3);
 }
 
-__global__ void __launch_bounds__(256) k_paper_pack(NfParamPtrs ptrs, const uint32_t* __restrict__ table,
-                                                    float* __restrict__ packed, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t code = table[i];
-        const uint32_t id = code >> 24;
-        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-    }
-}
-
-// One gather table per device, uploaded on first use.
-static std::mutex g_table_mutex;
-static uint32_t* g_table_dev[64] = {nullptr};
-
-static int nf_get_table(uint32_t** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    std::lock_guard<std::mutex> lock(g_table_mutex);
-    if (!g_table_dev[dev]) {
-        std::vector<uint32_t> host;
-        nf_build_gather_table(host);
-        uint32_t* d = nullptr;
-        e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
-        e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { hipFree(d); return (int)e; }
-        g_table_dev[dev] = d;
-    }
-    *out = g_table_dev[dev];
-    return 0;
-}
+static NfPackTable g_paper_table;
 
 extern "C" size_t nf_paper_packed_floats(void) { return (size_t)nfl::PACKED_FLOATS; }
 // 2332 floats are written; the buffer is padded to 10 KiB so that the bf16 kernel can DMA it into LDS in whole KiB blocks
@@ -145,17 +114,7 @@ extern "C" int nf_paper_gather_table(uint32_t* out, size_t n) {
 }
 
 extern "C" int nf_paper_pack(const float* const* params, float* packed, nf_stream_t stream) {
-    if (!params || !packed) return NF_EINVAL;
-    NfParamPtrs ptrs;
-    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) {
-        if (!params[i]) return NF_EINVAL;
-        ptrs.p[i] = params[i];
-    }
-    uint32_t* table = nullptr;
-    const int rc = nf_get_table(&table);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_paper_pack, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, packed, (int)nfl::PACKED_FLOATS);
-    NF_RETURN_LAUNCH();
+    return nf_pack_f32<NF_PAPER_NUM_PARAMS, 0>(g_paper_table, nf_build_gather_table, params, packed, (int)nfl::PACKED_FLOATS, stream);
 }
 
 // =================================================================================================

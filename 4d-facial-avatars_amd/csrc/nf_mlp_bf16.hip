@@ -21,11 +21,11 @@
 #include <mutex>
 
 #include "nf_mlp_bf16_common.h"
+#include "nf_pack.h"
 
 // =================================================================================================
 // pack: fp32 parameters -> (hi, lo) bf16 fragment stream
 // =================================================================================================
-struct NfParamPtrsB { const float* p[NF_PAPER_NUM_PARAMS]; };
 static const uint32_t NF_ZERO_B = 0xFF000000u;
 
 static void nf_build_table_bf16(std::vector<uint32_t>& t) {
@@ -66,52 +66,12 @@ static void nf_build_table_bf16(std::vector<uint32_t>& t) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_paper_pack_bf16(NfParamPtrsB ptrs, const uint32_t* __restrict__ table,
-                                                         __bf16* __restrict__ stream, int n_entries) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
-        const uint32_t code = table[e];
-        const uint32_t id = code >> 24;
-        const float w = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-        const __bf16 hi = (__bf16)w;
-        const __bf16 lo = (__bf16)(w - (float)hi);
-        const int pair = e >> 9, within = e & 511;
-        stream[(size_t)(2 * pair) * 512 + within] = hi;
-        stream[(size_t)(2 * pair + 1) * 512 + within] = lo;
-    }
-}
-
-static std::mutex g_table_b_mutex;
-static uint32_t* g_table_b_dev[64] = {nullptr};
+static NfPackTable g_paper_table_b;
 
 extern "C" size_t nf_paper_packed_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }
 
 extern "C" int nf_paper_pack_bf16(const float* const* params, void* stream_out, nf_stream_t stream) {
-    if (!params || !stream_out) return NF_EINVAL;
-    NfParamPtrsB ptrs;
-    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) {
-        if (!params[i]) return NF_EINVAL;
-        ptrs.p[i] = params[i];
-    }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    {
-        std::lock_guard<std::mutex> lock(g_table_b_mutex);
-        if (!g_table_b_dev[dev]) {
-            std::vector<uint32_t> host;
-            nf_build_table_bf16(host);
-            uint32_t* d = nullptr;
-            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-            g_table_b_dev[dev] = d;
-        }
-    }
-    hipLaunchKernelGGL(k_paper_pack_bf16, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_table_b_dev[dev],
-                       reinterpret_cast<__bf16*>(stream_out), nfb::N_PAIRS * 512);
-    NF_RETURN_LAUNCH();
+    return nf_pack_split_bf16<NF_PAPER_NUM_PARAMS, 2>(g_paper_table_b, nf_build_table_bf16, params, stream_out, nfb::N_PAIRS * 512, stream);
 }
 
 #define NFB_SAVE 0

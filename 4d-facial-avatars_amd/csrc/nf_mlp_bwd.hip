@@ -15,8 +15,8 @@
 #include <mutex>
 #include "nf_mlp_dev.h"
 #include "nf_mlp_dw.h"
+#include "nf_pack.h"
 
-struct NfParamPtrs26 { const float* p[NF_PAPER_NUM_PARAMS]; };
 
 // =================================================================================================
 // transposed pack
@@ -53,52 +53,12 @@ static void nf_build_gather_table_t(std::vector<uint32_t>& t) {
     nf_fill_layer_t(t, OFFT_L1, 16, 16, 2, 256, 256, 0);
 }
 
-__global__ void __launch_bounds__(256) k_paper_pack_t(NfParamPtrs26 ptrs, const uint32_t* __restrict__ table,
-                                                      float* __restrict__ packed, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t code = table[i];
-        const uint32_t id = code >> 24;
-        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-    }
-}
-
-static std::mutex g_table_t_mutex;
-static uint32_t* g_table_t_dev[64] = {nullptr};
-
-static int nf_get_table_t(uint32_t** out) {
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    std::lock_guard<std::mutex> lock(g_table_t_mutex);
-    if (!g_table_t_dev[dev]) {
-        std::vector<uint32_t> host;
-        nf_build_gather_table_t(host);
-        uint32_t* d = nullptr;
-        e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-        if (e != hipSuccess) return (int)e;
-        e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-        if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-        g_table_t_dev[dev] = d;
-    }
-    *out = g_table_t_dev[dev];
-    return 0;
-}
+static NfPackTable g_paper_table_t;
 
 extern "C" size_t nf_paper_packed_bwd_floats(void) { return (size_t)nfl::PACKED_T_FLOATS; }
 
 extern "C" int nf_paper_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream) {
-    if (!params || !packed_t) return NF_EINVAL;
-    NfParamPtrs26 ptrs;
-    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) {
-        if (!params[i]) return NF_EINVAL;
-        ptrs.p[i] = params[i];
-    }
-    uint32_t* table = nullptr;
-    const int rc = nf_get_table_t(&table);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_paper_pack_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, packed_t, (int)nfl::PACKED_T_FLOATS);
-    NF_RETURN_LAUNCH();
+    return nf_pack_f32<NF_PAPER_NUM_PARAMS, 1>(g_paper_table_t, nf_build_gather_table_t, params, packed_t, (int)nfl::PACKED_T_FLOATS, stream);
 }
 
 // =================================================================================================

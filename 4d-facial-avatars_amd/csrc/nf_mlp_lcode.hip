@@ -8,9 +8,9 @@
 #include <mutex>
 #include "nf_mlp_dev.h"
 #include "nf_mlp_lcode_layout.h"
+#include "nf_pack.h"
 
 
-struct NfLcodePtrs { const float* p[nlc::NPARAMS]; };
 
 static void nf_lcode_table(std::vector<uint32_t>& t) {
     using namespace nlc;
@@ -53,43 +53,14 @@ static void nf_lcode_table(std::vector<uint32_t>& t) {
     for (int n = 0; n < 3; ++n) t[OFF_BIAS + B_RGB + n] = code(13, 0, n, 3);
 }
 
-__global__ void __launch_bounds__(256) k_lcode_pack(NfLcodePtrs ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t code = table[i], id = code >> 24;
-        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-    }
-}
-
-static std::mutex g_lcode_mutex;
-static uint32_t* g_lcode_table[64] = {nullptr};
+static NfPackTable g_lcode_table;
 
 extern "C" size_t nf_lcode_packed_floats(void) { return (size_t)nlc::PACKED; }
 // padded to 10 KiB: the split-bf16 kernel stages the table into LDS with ten 1-KiB DMA pieces
 extern "C" size_t nf_lcode_cond_floats(void) { return 2560; }
 
 extern "C" int nf_lcode_pack(const float* const* params, float* packed, nf_stream_t stream) {
-    if (!params || !packed) return NF_EINVAL;
-    NfLcodePtrs ptrs;
-    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    {
-        std::lock_guard<std::mutex> lock(g_lcode_mutex);
-        if (!g_lcode_table[dev]) {
-            std::vector<uint32_t> host;
-            nf_lcode_table(host);
-            uint32_t* d = nullptr;
-            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-            g_lcode_table[dev] = d;
-        }
-    }
-    hipLaunchKernelGGL(k_lcode_pack, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_table[dev], packed, (int)nlc::PACKED);
-    NF_RETURN_LAUNCH();
+    return nf_pack_f32<nlc::NPARAMS, 4>(g_lcode_table, nf_lcode_table, params, packed, (int)nlc::PACKED, stream);
 }
 
 __global__ void __launch_bounds__(256) k_lcode_condition(const float* __restrict__ packed, const float* __restrict__ expr,

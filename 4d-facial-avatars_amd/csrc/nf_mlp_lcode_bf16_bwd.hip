@@ -25,11 +25,11 @@ __host__ __device__ constexpr int hid_feature(int s, int h, int j) { return 16 *
 }  // namespace nfb
 
 #include "nf_mlp_bf16_machinery.inc"
+#include "nf_pack.h"
 
 // =================================================================================================
 // transposed (hi, lo) stream: block (s, nt), lane (h', i), j  ->  W[row = reduction feature(s, h', j)][col = 32 nt + i]
 // =================================================================================================
-struct NfLcodePtrsBT { const float* p[nlc::NPARAMS]; };
 
 static void nf_lcode_table_bf16_t(std::vector<uint32_t>& t) {
     using namespace nfb;
@@ -58,48 +58,12 @@ static void nf_lcode_table_bf16_t(std::vector<uint32_t>& t) {
                     }
 }
 
-__global__ void __launch_bounds__(256) k_lcode_pack_bf16_t(NfLcodePtrsBT ptrs, const uint32_t* __restrict__ table,
-                                                           __bf16* __restrict__ stream, int n_entries) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
-        const uint32_t code = table[e], id = code >> 24;
-        const float w = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-        const __bf16 hi = (__bf16)w;
-        const __bf16 lo = (__bf16)(w - (float)hi);
-        const int pair = e >> 9, within = e & 511;
-        stream[(size_t)(2 * pair) * 512 + within] = hi;
-        stream[(size_t)(2 * pair + 1) * 512 + within] = lo;
-    }
-}
-
-static std::mutex g_lcode_bt_mutex;
-static uint32_t* g_lcode_bt_table[64] = {nullptr};
+static NfPackTable g_lcode_table_bt;
 
 extern "C" size_t nf_lcode_packed_bwd_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }
 
 extern "C" int nf_lcode_pack_bwd_bf16(const float* const* params, void* stream_out, nf_stream_t stream) {
-    if (!params || !stream_out) return NF_EINVAL;
-    NfLcodePtrsBT ptrs;
-    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    {
-        std::lock_guard<std::mutex> lock(g_lcode_bt_mutex);
-        if (!g_lcode_bt_table[dev]) {
-            std::vector<uint32_t> host;
-            nf_lcode_table_bf16_t(host);
-            uint32_t* d = nullptr;
-            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-            g_lcode_bt_table[dev] = d;
-        }
-    }
-    hipLaunchKernelGGL(k_lcode_pack_bf16_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_bt_table[dev],
-                       reinterpret_cast<__bf16*>(stream_out), nfb::N_PAIRS * 512);
-    NF_RETURN_LAUNCH();
+    return nf_pack_split_bf16<nlc::NPARAMS, 7>(g_lcode_table_bt, nf_lcode_table_bf16_t, params, stream_out, nfb::N_PAIRS * 512, stream);
 }
 
 // =================================================================================================

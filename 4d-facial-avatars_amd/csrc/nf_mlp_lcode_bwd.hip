@@ -11,8 +11,8 @@
 #include "nf_mlp_dev.h"
 #include "nf_mlp_lcode_layout.h"
 #include "nf_mlp_dw.h"
+#include "nf_pack.h"
 
-struct NfLcodePtrsB { const float* p[nlc::NPARAMS]; };
 
 // =================================================================================================
 // transposed pack: block (ni, no), lane (g, i), r -> W[row = 16 ni + 4 g + r][col = 16 no + i]
@@ -39,41 +39,12 @@ static void nf_lcode_table_t(std::vector<uint32_t>& t) {
     fill(OFFT_X0, 16, 16, 2, 256, 256);
 }
 
-__global__ void __launch_bounds__(256) k_lcode_pack_t(NfLcodePtrsB ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t code = table[i], id = code >> 24;
-        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-    }
-}
-
-static std::mutex g_lcode_t_mutex;
-static uint32_t* g_lcode_t_table[64] = {nullptr};
+static NfPackTable g_lcode_table_t;
 
 extern "C" size_t nf_lcode_packed_bwd_floats(void) { return (size_t)nlc::PACKED_T; }
 
 extern "C" int nf_lcode_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream) {
-    if (!params || !packed_t) return NF_EINVAL;
-    NfLcodePtrsB ptrs;
-    for (int i = 0; i < nlc::NPARAMS; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    {
-        std::lock_guard<std::mutex> lock(g_lcode_t_mutex);
-        if (!g_lcode_t_table[dev]) {
-            std::vector<uint32_t> host;
-            nf_lcode_table_t(host);
-            uint32_t* d = nullptr;
-            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-            g_lcode_t_table[dev] = d;
-        }
-    }
-    hipLaunchKernelGGL(k_lcode_pack_t, dim3(1024), dim3(256), 0, nf_s(stream), ptrs, g_lcode_t_table[dev], packed_t, (int)nlc::PACKED_T);
-    NF_RETURN_LAUNCH();
+    return nf_pack_f32<nlc::NPARAMS, 5>(g_lcode_table_t, nf_lcode_table_t, params, packed_t, (int)nlc::PACKED_T, stream);
 }
 
 // =================================================================================================

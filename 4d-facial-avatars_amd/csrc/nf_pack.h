@@ -1,0 +1,95 @@
+// Weight packing shared by the model families and arithmetics: a gather table (one 32-bit code per packed element:
+// tensor id << 24 | element offset, 0xFF000000 = zero) is built on the host once per device, uploaded, and a one-pass
+// kernel gathers the live nn.Parameter storages into the MFMA fragment image -- f32 as is, or split into (hi, lo) bf16
+// 1-KiB block pairs for the split-bf16 kernels.  Runs again whenever a parameter's version counter moves (nerf/ops.py).
+#pragma once
+#include <vector>
+#include <mutex>
+#include "nf_common.h"
+
+template <int N>
+struct NfPackPtrs { const float* p[N]; };
+
+// TAG only keeps the instantiations of different translation units apart
+template <int N, int TAG>
+__global__ void __launch_bounds__(256) k_pack_f32(NfPackPtrs<N> ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t code = table[i], id = code >> 24;
+        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+    }
+}
+
+// entry e = (pair e >> 9, position e & 511): hi goes to block 2 * pair, lo = bf16(w - hi) to block 2 * pair + 1
+template <int N, int TAG>
+__global__ void __launch_bounds__(256) k_pack_split_bf16(NfPackPtrs<N> ptrs, const uint32_t* __restrict__ table, __bf16* __restrict__ stream,
+                                                         int n_entries) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+        const uint32_t code = table[e], id = code >> 24;
+        const float w = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
+        const __bf16 hi = (__bf16)w;
+        const __bf16 lo = (__bf16)(w - (float)hi);
+        const int pair = e >> 9, within = e & 511;
+        stream[(size_t)(2 * pair) * 512 + within] = hi;
+        stream[(size_t)(2 * pair + 1) * 512 + within] = lo;
+    }
+}
+
+// per-device copy of a gather table, built and uploaded on first use
+struct NfPackTable {
+    std::mutex mutex;
+    uint32_t* dev[64] = {nullptr};
+    template <class Build>
+    int get(Build build, uint32_t** out) {
+        int d = 0;
+        hipError_t e = hipGetDevice(&d);
+        if (e != hipSuccess) return (int)e;
+        if (d < 0 || d >= 64) return NF_EINVAL;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (!dev[d]) {
+            std::vector<uint32_t> host;
+            build(host);
+            uint32_t* p = nullptr;
+            e = hipMalloc(&p, host.size() * sizeof(uint32_t));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemcpy(p, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+            dev[d] = p;
+        }
+        *out = dev[d];
+        return 0;
+    }
+};
+
+template <int N>
+static inline int nf_pack_ptrs(const float* const* params, NfPackPtrs<N>& ptrs) {
+    if (!params) return NF_EINVAL;
+    for (int i = 0; i < N; ++i) {
+        if (!params[i]) return NF_EINVAL;
+        ptrs.p[i] = params[i];
+    }
+    return 0;
+}
+
+template <int N, int TAG, class Build>
+static inline int nf_pack_f32(NfPackTable& cache, Build build, const float* const* params, float* packed, int n, nf_stream_t stream) {
+    NfPackPtrs<N> ptrs;
+    if (!packed || nf_pack_ptrs<N>(params, ptrs)) return NF_EINVAL;
+    uint32_t* table = nullptr;
+    const int rc = cache.get(build, &table);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_pack_f32<N, TAG>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, packed, n);
+    NF_RETURN_LAUNCH();
+}
+
+template <int N, int TAG, class Build>
+static inline int nf_pack_split_bf16(NfPackTable& cache, Build build, const float* const* params, void* stream_out, int n_entries,
+                                     nf_stream_t stream) {
+    NfPackPtrs<N> ptrs;
+    if (!stream_out || nf_pack_ptrs<N>(params, ptrs)) return NF_EINVAL;
+    uint32_t* table = nullptr;
+    const int rc = cache.get(build, &table);
+    if (rc) return rc;
+    hipLaunchKernelGGL((k_pack_split_bf16<N, TAG>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, reinterpret_cast<__bf16*>(stream_out),
+                       n_entries);
+    NF_RETURN_LAUNCH();
+}

@@ -5,6 +5,7 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_pack.h"
 
 namespace nft {
 constexpr int FRAG = 256;
@@ -15,7 +16,6 @@ constexpr int OFF_B = OFF_3 + 8 * 1 * FRAG;      // biases: 128 | 128 | 16
 constexpr int PACKED = OFF_B + 128 + 128 + 16;
 }  // namespace nft
 
-struct NfTinyPtrs { const float* p[6]; };        // layer1.weight, layer1.bias, layer2.weight, layer2.bias, layer3.weight, layer3.bias
 
 static void nf_tiny_table(std::vector<uint32_t>& t) {
     using namespace nft;
@@ -39,41 +39,12 @@ static void nf_tiny_table(std::vector<uint32_t>& t) {
     for (int n = 0; n < 4; ++n) t[OFF_B + 256 + n] = (5u << 24) | n;
 }
 
-__global__ void __launch_bounds__(256) k_tiny_pack(NfTinyPtrs ptrs, const uint32_t* __restrict__ table, float* __restrict__ packed, int n) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-        const uint32_t code = table[i], id = code >> 24;
-        packed[i] = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu];
-    }
-}
-
-static std::mutex g_tiny_mutex;
-static uint32_t* g_tiny_table[64] = {nullptr};
+static NfPackTable g_tiny_table;
 
 extern "C" size_t nf_tiny_packed_floats(void) { return (size_t)nft::PACKED; }
 
 extern "C" int nf_tiny_pack(const float* const* params, float* packed, nf_stream_t stream) {
-    if (!params || !packed) return NF_EINVAL;
-    NfTinyPtrs ptrs;
-    for (int i = 0; i < 6; ++i) { if (!params[i]) return NF_EINVAL; ptrs.p[i] = params[i]; }
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return (int)e;
-    if (dev < 0 || dev >= 64) return NF_EINVAL;
-    {
-        std::lock_guard<std::mutex> lock(g_tiny_mutex);
-        if (!g_tiny_table[dev]) {
-            std::vector<uint32_t> host;
-            nf_tiny_table(host);
-            uint32_t* d = nullptr;
-            e = hipMalloc(&d, host.size() * sizeof(uint32_t));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(d, host.data(), host.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(d); return (int)e; }
-            g_tiny_table[dev] = d;
-        }
-    }
-    hipLaunchKernelGGL(k_tiny_pack, dim3(64), dim3(256), 0, nf_s(stream), ptrs, g_tiny_table[dev], packed, (int)nft::PACKED);
-    NF_RETURN_LAUNCH();
+    return nf_pack_f32<6, 8>(g_tiny_table, nf_tiny_table, params, packed, (int)nft::PACKED, stream);
 }
 
 template <int NT>
