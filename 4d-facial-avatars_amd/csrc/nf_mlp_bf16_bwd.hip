@@ -3,7 +3,7 @@
 // in registers from layer to layer, the TRANSPOSED weight stream (hi, lo fragment blocks) is staged L2 -> LDS through the same
 // 4-deep ring.  ReLU masks come as bit masks written by the split-bf16 training forward (one 16-byte load per layer, all
 // issued before the ring starts, so that no ordinary load sits in the pipelined part); every dZ_l is written to HBM in f32 for
-// the weight-gradient GEMMs (nf_mlp_bwd.hip: k_paper_dw_gemm), which stay exact f32.
+// the weight-gradient GEMMs (split-bf16: nf_mlp_bf16_dw.hip; exact f32: nf_mlp_dw.h).
 #include <vector>
 #include <mutex>
 #include "nf_common.h"

@@ -1,6 +1,6 @@
 // B2, split-bf16 variant: the weight-gradient GEMMs  dW = dZ^T . X  on the bf16 matrix pipe at fp32-class accuracy.
 //
-// Same inputs and outputs as k_paper_dw_gemm (nf_mlp_bwd.hip): dZ sections [n_points][width] written by the backward
+// Same inputs and outputs as the exact-f32 k_dw_gemm (nf_mlp_dw.h): dZ sections [n_points][width] written by the backward
 // chain, d_raw [n_points][4], the activations saved by the training forward, and per-slice 594k-float slabs of partial
 // dW / column sums that B3 reduces.  What changes is the arithmetic and the data movement:
 //   * every operand value x is split into bf16 (hi, lo) and each 32x32 output tile takes three

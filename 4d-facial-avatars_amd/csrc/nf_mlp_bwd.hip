@@ -5,7 +5,7 @@
 //   B1  k_paper_mlp_bwd_chain   per 32-point wave tile, the forward kernel run in reverse on a transposed
 //                               fragment image: dZ_l = (dZ_{l+1} . W_{l+1}) * [X_l > 0]; masks come from the
 //                               activations the training forward saved; every dZ_l is written to HBM.
-//   B2  k_paper_dw_gemm         dW_l = dZ_l^T . X_{l-1} as wave-level 128x128 output tiles with the point
+//   B2  k_dw_gemm (nf_mlp_dw.h)  dW_l = dZ_l^T . X_{l-1} as wave-level 128x128 output tiles with the point
 //                               dimension (hundreds of thousands) split into slices; bias grads (column sums
 //                               of dZ) fall out of the A fragments.  Deterministic: partial slabs per slice.
 //   B3  k_paper_grad_reduce /   sum the slabs over slices, then scatter into the 26 reference-layout tensors:
