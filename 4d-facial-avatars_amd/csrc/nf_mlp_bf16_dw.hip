@@ -18,6 +18,7 @@
 //               (the MFMA contraction index is the point); bias gradients (column sums of dZ) are accumulated here
 //               in f32,
 //       M(i-1)  2 + 2 fragment pairs per wave (conflict-free ds_read_b128), 12 MFMAs, branch-free.
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -397,10 +398,11 @@ int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const flo
     NF_RETURN_LAUNCH();
 }
 
-// slices for the split-bf16 dW kernel: about 504 workgroups = two rounds of the 256 CUs (paper: 11 bundles x 46 slices,
-// second family: 8 bundles x 63 slices)
+// slices for the split-bf16 dW kernel: one workgroup per CU (paper: 11 bundles x 23 slices = 253 workgroups, second family:
+// 8 x 32 = 256); two rounds (46 slices) measured 2 % slower end to end (twice the slab traffic), three rounds slower still
 void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
-    const int target = model == 0 ? 46 : 63;
+    int target = model == 0 ? 23 : 32;
+    if (const char* ev = getenv("NERFACE_DW_SLICES")) { const int v = atoi(ev); if (v >= 1 && v <= 512) target = v; }   // tuning knob
     int64_t pps = (n_points + target - 1) / target;
     pps = (pps + 15) / 16 * 16;
     if (pps < 256) pps = 256;
