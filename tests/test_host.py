@@ -154,6 +154,22 @@ def test_product_has_no_cpu_path():
         m(torch.zeros(2, 87), torch.zeros(76), torch.zeros(32))               # CPU tensors: no CPU path
 
 
+def test_oracle_is_imported_only_by_the_checkers():
+    """oracle/ is test infrastructure: nothing in the product package, the launchers or tools/ may import it; bench.py may only
+    inside its cpu_baseline leg (function cpu_baseline) and __graft_entry__ only as the smoke() / build() checker."""
+    pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
+    for base in ("4d-facial-avatars_amd", "tools"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(src), os.path.join(dirpath, f)
+    bench = open(os.path.join(ROOT, "bench.py")).read()
+    leg = bench[bench.index("def cpu_baseline("):]
+    leg = leg[:leg.index("\ndef ", 1)]
+    assert len(pat.findall(bench)) == len(pat.findall(leg)) > 0
+
+
 def test_cfgnode_roundtrip():
     import yaml
     import nerf

@@ -10,8 +10,19 @@ from PIL import Image
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from oracle import nerface_oracle as O  # noqa: E402  (pose helper only)
 
+
+def frame_pose(f):
+    """Camera-to-world matrix of synthetic frame f: a small yaw / pitch orbit 0.5 in front of the head."""
+    import math
+    a = 0.3 * math.sin(2 * math.pi * f / 100.0)
+    b = 0.15 * math.cos(2 * math.pi * f / 100.0)
+    ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
+    rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
+    m = np.eye(4)
+    m[:3, :3] = ry @ rx
+    m[:3, 3] = [0.02 * math.sin(2 * math.pi * f / 100.0), 0.02 * math.cos(2 * math.pi * f / 100.0), 0.5]
+    return m
 
 def write(basedir, size=32, n_train=6, n_val=2, n_test=3, seed=0):
     rng = np.random.RandomState(seed)
@@ -27,7 +38,7 @@ def write(basedir, size=32, n_train=6, n_val=2, n_test=3, seed=0):
             img = (0.5 * bg + 0.5 * rng.rand(size, size, 3) * 255).astype(np.uint8)
             name = f"{split}/f_{k:04d}"
             Image.fromarray(img).save(os.path.join(basedir, name + ".png"))
-            frames.append({"file_path": name, "bbox": [0.25, 0.75, 0.25, 0.75], "transform_matrix": O.frame_pose(f).tolist(),
+            frames.append({"file_path": name, "bbox": [0.25, 0.75, 0.25, 0.75], "transform_matrix": frame_pose(f).tolist(),
                            "expression": (0.5 * rng.randn(76)).tolist()})
             if split == "test":
                 index_map.append([k, k % n_train])
