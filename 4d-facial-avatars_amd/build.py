@@ -34,10 +34,24 @@ def _stale() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+def _includes(src: str, seen=None) -> set:
+    """Transitive `#include "..."` closure of one source (so that an edit recompiles only the units that see it)."""
+    import re
+    seen = set() if seen is None else seen
+    if src in seen or not os.path.exists(src):
+        return seen
+    seen.add(src)
+    for m in re.finditer(r'^\s*#\s*include\s+"([^"]+)"', open(src).read(), re.M):
+        _includes(os.path.normpath(os.path.join(os.path.dirname(src), m.group(1))), seen)
+    return seen
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
     if not force and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
+    obj_dir = os.path.join(OUT_DIR, "obj")                      # object cache (git-ignored): incremental rebuilds
+    os.makedirs(obj_dir, exist_ok=True)
     objs = []
     cc = _hipcc()
     procs = []
@@ -45,8 +59,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
         src = os.path.join(SRC, s)
         if not os.path.exists(src):
             continue
-        obj = os.path.join(OUT_DIR, s.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, s.replace(".hip", ".o"))
         objs.append(obj)
+        newest = max(os.path.getmtime(d) for d in _includes(src) | {os.path.abspath(__file__)})
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
+            continue
         procs.append((s, subprocess.Popen([cc, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         try:
@@ -62,8 +79,6 @@ def build(force: bool = False, verbose: bool = True) -> str:
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:
         raise RuntimeError("link failed:\n" + r.stdout.decode())
-    for o in objs:
-        os.remove(o)
     if verbose:
         print("built", OUT)
     return OUT

@@ -239,25 +239,60 @@ extern "C" int nf_volume_render_bwd(const float* raw, const float* z, const floa
 //   cdf[0] = 0, cdf[i] = cumsum((w+1e-5)/sum(w+1e-5))[i-1];  idx = #{cdf <= u} (searchsorted right=True)
 // `lds_cdf`/`lds_bins` are this wave's tables (n_bins entries each); returns via callback-free loop.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void nf_build_cdf(const float* __restrict__ w_row, int n_w, float* lds_cdf) {
+// The table is BIT-IDENTICAL to what torch's CPU kernels give the reference (H:349-353), so that searchsorted lands in the
+// same bin for every u (tests/test_gpu_kernels.py::test_sample_pdf_bit_exact):
+//   * torch.sum over a contiguous float row (ATen SumKernel, vectorized_inner_sum): 8-lane vector partial sums with 4-way
+//     ILP -- P[k][l] accumulates x[(4i+k)*8+l], leftover whole vectors go to P[0], P[0] += P[1..3], then a scalar
+//     accumulator takes the tail elements and finally the 8 lanes of P[0], all in float; rows shorter than one vector use
+//     the same scheme on scalars (row_sum);
+//   * torch.cumsum (cumsum_cpu_kernel): one sequential accumulator in DOUBLE, rounded to float per element.
+// Every wave of the block must call this (it contains block barriers); `on` = this wave has a ray.
+__device__ __forceinline__ void nf_build_cdf(const float* __restrict__ w_row, int n_w, float* lds_cdf, bool on) {
     const int lane = nf_lane();
-    float part = 0.0f;
-    for (int i = lane; i < n_w; i += 64) part += nf_add(w_row[i], 1e-5f);
-    const float sum = wave_sum(part);
-    float carry = 0.0f;
-    if (lane == 0) lds_cdf[0] = 0.0f;
-    for (int base = 0; base < n_w; base += 64) {
-        const int i = base + lane;
-        const float pdf = i < n_w ? nf_div(nf_add(w_row[i], 1e-5f), sum) : 0.0f;
-        const float incl = wave_scan_add(pdf);
-        if (i < n_w) lds_cdf[i + 1] = carry + incl;
-        carry += __shfl(incl, 63, 64);
+    float* x = lds_cdf + 1;                                     // x[i] = w[i] + 1e-5, later pdf[i], later cdf[i+1]
+    if (on) for (int i = lane; i < n_w; i += 64) x[i] = nf_add(w_row[i], 1e-5f);
+    __syncthreads();
+    float sum = 0.0f;
+    if (on) {
+        if (n_w < 8) {
+            if (lane == 0) {
+                float p[4] = {0.f, 0.f, 0.f, 0.f};
+                const int q = n_w >> 2;
+                for (int i = 0; i < q; ++i)
+                    for (int k = 0; k < 4; ++k) p[k] = nf_add(p[k], x[4 * i + k]);
+                for (int i = q * 4; i < n_w; ++i) p[0] = nf_add(p[0], x[i]);
+                sum = nf_add(nf_add(nf_add(p[0], p[1]), p[2]), p[3]);
+            }
+        } else {
+            const int V = n_w >> 3, q = V >> 2, k = (lane >> 3) & 3, l = lane & 7;
+            float P = 0.0f;                                     // lanes 0..31: P[k][l]
+            for (int i = 0; i < q; ++i) P = nf_add(P, x[((4 * i + k) << 3) + l]);
+            if (k == 0) for (int i = q * 4; i < V; ++i) P = nf_add(P, x[(i << 3) + l]);
+            const float p1 = __shfl(P, 8 + l, 64), p2 = __shfl(P, 16 + l, 64), p3 = __shfl(P, 24 + l, 64);
+            P = nf_add(nf_add(nf_add(P, p1), p2), p3);          // meaningful in lanes 0..7
+            float fin = 0.0f;
+            for (int i = V << 3; i < n_w; ++i) fin = nf_add(fin, x[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) fin = nf_add(fin, __shfl(P, j, 64));
+            sum = fin;
+        }
+        sum = __shfl(sum, 0, 64);
+    }
+    __syncthreads();
+    if (on) for (int i = lane; i < n_w; i += 64) x[i] = nf_div(x[i], sum);
+    __syncthreads();
+    if (on && lane == 0) {
+        lds_cdf[0] = 0.0f;
+        double acc = 0.0;
+        for (int i = 0; i < n_w; ++i) { acc += (double)x[i]; x[i] = (float)acc; }
     }
 }
 
-__device__ __forceinline__ float nf_invert_cdf(const float* lds_cdf, const float* lds_bins, int n_bins, float u) {
+__device__ __forceinline__ float nf_invert_cdf(const float* lds_cdf, const float* lds_bins, int n_bins, float u,
+                                               int* idx_out = nullptr) {
     int lo = 0, hi = n_bins;                   // first index with cdf > u  (== count of cdf <= u)
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (lds_cdf[mid] <= u) lo = mid + 1; else hi = mid; }
+    if (idx_out) *idx_out = lo;                // torch.searchsorted(cdf, u, right=True), H:368
     const int below = lo - 1 > 0 ? lo - 1 : 0;
     const int above = lo < n_bins - 1 ? lo : n_bins - 1;
     const float cb = lds_cdf[below], ca = lds_cdf[above];
@@ -270,31 +305,41 @@ __device__ __forceinline__ float nf_invert_cdf(const float* lds_cdf, const float
 
 __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bins, const float* __restrict__ weights,
                                                     const float* __restrict__ u, int64_t u_stride, int64_t n_rays,
-                                                    int n_bins, int n_out, float* __restrict__ samples) {
+                                                    int n_bins, int n_out, float* __restrict__ samples,
+                                                    int* __restrict__ inds_out, float* __restrict__ cdf_out) {
     __shared__ float lds[NF_RAYS_PER_BLOCK][2 * NF_MAX_BINS];
     const int lane = nf_lane(), wv = threadIdx.x >> 6;
     const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
     float* cdf = lds[wv];
     float* lb = lds[wv] + NF_MAX_BINS;
-    if (ray < n_rays) {
-        nf_build_cdf(weights + ray * (n_bins - 1), n_bins - 1, cdf);
-        for (int i = lane; i < n_bins; i += 64) lb[i] = bins[ray * n_bins + i];
-    }
+    const bool on = ray < n_rays;
+    nf_build_cdf(weights + ray * (n_bins - 1), n_bins - 1, cdf, on);
+    if (on) for (int i = lane; i < n_bins; i += 64) lb[i] = bins[ray * n_bins + i];
     __syncthreads();
-    if (ray < n_rays)
-        for (int j = lane; j < n_out; j += 64)
-            samples[ray * n_out + j] = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j]);
+    if (on) {
+        for (int j = lane; j < n_out; j += 64) {
+            int idx;
+            samples[ray * n_out + j] = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j], &idx);
+            if (inds_out) inds_out[ray * n_out + j] = idx;
+        }
+        if (cdf_out) for (int i = lane; i < n_bins; i += 64) cdf_out[ray * n_bins + i] = cdf[i];
+    }
 }
 
-extern "C" int nf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
-                             int n_bins, int n_out, float* samples, nf_stream_t stream) {
+extern "C" int nf_sample_pdf_ex(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
+                                int n_bins, int n_out, float* samples, int* inds, float* cdf, nf_stream_t stream) {
     if (!bins || !weights || !u || !samples || n_rays < 0 || n_bins < 2 || n_bins > NF_MAX_BINS || n_out <= 0) return NF_EINVAL;
     if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), bins, weights, u, u_row_stride, n_rays,
-                       n_bins, n_out, samples);
+                       n_bins, n_out, samples, inds, cdf);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
+                             int n_bins, int n_out, float* samples, nf_stream_t stream) {
+    return nf_sample_pdf_ex(bins, weights, u, u_row_stride, n_rays, n_bins, n_out, samples, nullptr, nullptr, stream);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -358,8 +403,8 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
     float* lb = lds[wv] + NF_MAX_BINS;
     float* srt = lds[wv] + 2 * NF_MAX_BINS;
     const int n_bins = nc - 1, nt = nc + nf, np2 = nf_next_pow2(nt);
+    nf_build_cdf(wc + ray * nc + 1, nc - 2, cdf, on);
     if (on) {
-        nf_build_cdf(wc + ray * nc + 1, nc - 2, cdf);
         for (int i = lane; i < nc; i += 64) {
             const float zi = zc[ray * nc + i];
             srt[i] = zi;

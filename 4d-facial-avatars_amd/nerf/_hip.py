@@ -81,6 +81,7 @@ _PROTOTYPES = {
     "nf_volume_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "nf_volume_render_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "nf_sample_pdf": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
+    "nf_sample_pdf_ex": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P]),
     "nf_resample_merge": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "nf_render_rays_workspace_floats": (_Z, [_L, _I, _I]),
     "nf_render_rays_fwd": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),

@@ -309,17 +309,20 @@ def _u_arg(u: Optional[torch.Tensor], n_rays: int, n_out: int, device):
     return u, n_out
 
 
-def sample_pdf(bins, weights, n_out: int, u: Optional[torch.Tensor] = None):
+def sample_pdf(bins, weights, n_out: int, u: Optional[torch.Tensor] = None, want_table: bool = False):
+    """sample_pdf_2 (H:344-387).  want_table: also return (inds int32 (R,n_out) = searchsorted(cdf, u, right=True), cdf (R,n_bins))."""
     bins, weights = _c(bins), _c(weights)
     dev = H.require_device(bins, weights)
     n_rays, n_bins = bins.shape
     assert weights.shape == (n_rays, n_bins - 1)
     u_t, stride = _u_arg(u, n_rays, n_out, dev)
     out = torch.empty((n_rays, n_out), dtype=torch.float32, device=dev)
+    inds = torch.empty((n_rays, n_out), dtype=torch.int32, device=dev) if want_table else None
+    cdf = torch.empty((n_rays, n_bins), dtype=torch.float32, device=dev) if want_table else None
     with torch.cuda.device(dev):
-        H.check(H.lib().nf_sample_pdf(H.ptr(bins), H.ptr(weights), H.ptr(u_t), stride, n_rays, n_bins, n_out, H.ptr(out),
-                                      H.stream_ptr(dev)), "nf_sample_pdf")
-    return out
+        H.check(H.lib().nf_sample_pdf_ex(H.ptr(bins), H.ptr(weights), H.ptr(u_t), stride, n_rays, n_bins, n_out, H.ptr(out),
+                                         H.ptr(inds), H.ptr(cdf), H.stream_ptr(dev)), "nf_sample_pdf_ex")
+    return (out, inds, cdf) if want_table else out
 
 
 def resample_merge(z_coarse, w_coarse, n_fine: int, u: Optional[torch.Tensor] = None, want_samples: bool = False):

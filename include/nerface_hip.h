@@ -196,6 +196,11 @@ int nf_eval_postprocess(const float* rgb, const float* depthmap, const float* we
  * (u_row_stride = n_out for torch.rand draws, 0 to broadcast the det-mode linspace(0,1,n_out) table). */
 int nf_sample_pdf(const float* bins, const float* weights, const float* u, int64_t u_row_stride,
                   int64_t n_rays, int n_bins, int n_out, float* samples, nf_stream_t stream);
+/* The CDF table is bit-identical to torch-CPU's (float row sum in ATen's 8-lane / 4-way-ILP order, sequential double
+ * cumsum rounded per element), so the searchsorted indices equal the reference's.  The _ex form also returns them:
+ * inds (R,n_out) int32 = torch.searchsorted(cdf, u, right=True) (H:368), cdf (R,n_bins); either may be NULL.           */
+int nf_sample_pdf_ex(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
+                     int n_bins, int n_out, float* samples, int* inds, float* cdf, nf_stream_t stream);
 
 /* ---- K6+K7 fused: hierarchical resampling -- replaces T:116-126 (z_mid, sample_pdf on w[1:-1],
  *      sort(cat(z, z_samples))) ---------------------------------------------------------------------- */

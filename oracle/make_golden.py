@@ -104,12 +104,59 @@ def make_lcode_grads(ref):
     print("lcode grad fixture: loss", float(loss), "latent |g|", float(latent.grad.norm()))
 
 
+def make_pe_pdf(ref):
+    """positional encoding + sample_pdf_2 (H:344-387) incl. edge cases.  The reference returns only the samples; the CDF
+    table and the searchsorted indices stored next to them come from the oracle restatement AFTER it reproduced the
+    reference's samples bit for bit on the same inputs (asserted here)."""
+    g = torch.Generator().manual_seed(5)
+    x = (torch.rand((33, 3), generator=g) - 0.5) * 1.6
+    pe10 = ref.positional_encoding(x, 10, True, True)
+    pe4 = ref.positional_encoding(x, 4, False, True)
+    tu = sys.modules["_ref_nerf.train_utils"]
+    bins = torch.sort(torch.rand((6, 63), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    w = torch.rand((6, 62), generator=g)
+    w[1] = 0.0                      # all-zero weights -> uniform pdf
+    w[2, :30] = 0.0
+    w[2, 31:] = 0.0                 # single spike
+    w[3] = 1.0                      # uniform
+    uu = torch.rand((6, 128), generator=g)
+    uu[4, :4] = torch.tensor([0.0, 1.0, 0.5, 0.999999])
+    with RI.injected_random([uu], []):
+        zs_rand = tu.sample_pdf(bins, w, 128, det=False)
+    zs_det = tu.sample_pdf(bins, w, 128, det=True)
+    tr, td = {}, {}
+    assert torch.equal(O.sample_pdf(bins, w, 128, uu, table=tr), zs_rand) and torch.equal(O.sample_pdf(bins, w, 128, None, table=td), zs_det)
+    blob = dict(x=x.numpy(), pe10=pe10.numpy(), pe4=pe4.numpy(), bins=bins.numpy(), w=w.numpy(), u=uu.numpy(),
+                zs_rand=zs_rand.numpy(), zs_det=zs_det.numpy(), cdf=tr["cdf"].numpy(), inds_rand=tr["inds"].numpy().astype(np.int32),
+                inds_det=td["inds"].numpy().astype(np.int32))
+    # other table widths: 3 weights (the ragged 5+7 case: torch's scalar row-sum path), 190 (192 coarse samples), 9, 17;
+    # compositing-like weights (a few large entries, many exact zeros), 48 rays each
+    for nb in (4, 10, 18, 63, 191):
+        gg = torch.Generator().manual_seed(100 + nb)
+        b = torch.sort(torch.rand((48, nb), generator=gg) * 0.6 + 0.2, dim=-1)[0]
+        ww = torch.rand((48, nb - 1), generator=gg) ** 6
+        ww[ww < 0.05] = 0.0
+        ww = ww / ww.sum(-1, keepdim=True).clamp(min=0.5)
+        u2 = torch.rand((48, 64), generator=gg)
+        with RI.injected_random([u2], []):
+            z2 = tu.sample_pdf(b, ww, 64, det=False)
+        t2 = {}
+        assert torch.equal(O.sample_pdf(b, ww, 64, u2, table=t2), z2)
+        blob.update({f"b{nb}_bins": b.numpy(), f"b{nb}_w": ww.numpy(), f"b{nb}_u": u2.numpy(), f"b{nb}_zs": z2.numpy(),
+                     f"b{nb}_inds": t2["inds"].numpy().astype(np.int32), f"b{nb}_cdf": t2["cdf"].numpy()})
+    np.savez_compressed(os.path.join(OUT, "pe_pdf.npz"), **blob)
+    print("pe_pdf fixture written (oracle == reference samples, bit exact)")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     ref = RI.import_reference()
     torch.set_num_threads(8)
     if len(sys.argv) > 1 and sys.argv[1] == "lcode_grads":        # regenerate only this fixture
         make_lcode_grads(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "pe_pdf":
+        make_pe_pdf(ref)
         return
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     for name in C.CASES:
@@ -198,25 +245,7 @@ def main():
     ro_s, rd_s = ref.get_ray_bundle(24, 24, torch.tensor(138.88 * 24 / 100.0), pose)     # scalar-focal fallback (H:109)
     np.savez_compressed(os.path.join(OUT, "ray_bundle.npz"), rd=rd.numpy(), ro=ro.numpy(), rd_scalar=rd_s.numpy())
 
-    # positional encoding + sample_pdf edge cases
-    g = torch.Generator().manual_seed(5)
-    x = (torch.rand((33, 3), generator=g) - 0.5) * 1.6
-    pe10 = ref.positional_encoding(x, 10, True, True)
-    pe4 = ref.positional_encoding(x, 4, False, True)
-    tu = sys.modules["_ref_nerf.train_utils"]
-    bins = torch.sort(torch.rand((6, 63), generator=g) * 0.6 + 0.2, dim=-1)[0]
-    w = torch.rand((6, 62), generator=g)
-    w[1] = 0.0                      # all-zero weights -> uniform pdf
-    w[2, :30] = 0.0
-    w[2, 31:] = 0.0                 # single spike
-    w[3] = 1.0                      # uniform
-    uu = torch.rand((6, 128), generator=g)
-    uu[4, :4] = torch.tensor([0.0, 1.0, 0.5, 0.999999])
-    with RI.injected_random([uu], []):
-        zs_rand = tu.sample_pdf(bins, w, 128, det=False)
-    zs_det = tu.sample_pdf(bins, w, 128, det=True)
-    np.savez_compressed(os.path.join(OUT, "pe_pdf.npz"), x=x.numpy(), pe10=pe10.numpy(), pe4=pe4.numpy(),
-                        bins=bins.numpy(), w=w.numpy(), u=uu.numpy(), zs_rand=zs_rand.numpy(), zs_det=zs_det.numpy())
+    make_pe_pdf(ref)
 
     # tiny_nerf (BASELINE config 1): 64x64, 32 samples, 3-layer 128-wide MLP, coarse only
     TN = RI.import_reference_tiny()

@@ -270,8 +270,10 @@ def volume_render(raw: torch.Tensor, z: torch.Tensor, rd: torch.Tensor, noise: O
 # A9  inverse-CDF sampler                                                    (H:344-387)
 # --------------------------------------------------------------------------------------
 
-def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Optional[torch.Tensor] = None):
-    """bins (R,B), weights (R,B-1) -> (R,n_samples).  ``u=None`` is det mode: linspace(0,1,n) incl. 1.0."""
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Optional[torch.Tensor] = None,
+               table: Optional[dict] = None):
+    """bins (R,B), weights (R,B-1) -> (R,n_samples).  ``u=None`` is det mode: linspace(0,1,n) incl. 1.0.
+    ``table`` (a dict) collects the CDF and the searchsorted indices (H:353, H:368) for the K6 parity test."""
     w = weights + 1e-5
     pdf = w / w.sum(dim=-1, keepdim=True)
     cdf = torch.cumsum(pdf, dim=-1)
@@ -280,6 +282,8 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
         u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=w.dtype).expand(cdf.shape[0], n_samples)
     u = u.contiguous()
     idx = torch.searchsorted(cdf.contiguous(), u, right=True)
+    if table is not None:
+        table.update(cdf=cdf, inds=idx)
     lo = (idx - 1).clamp(min=0)
     hi = idx.clamp(max=cdf.shape[-1] - 1)
     c_lo, c_hi = torch.gather(cdf, 1, lo), torch.gather(cdf, 1, hi)
