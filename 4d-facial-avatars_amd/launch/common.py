@@ -16,19 +16,50 @@ import nerf  # noqa: E402
 from nerf import distributed as D  # noqa: E402
 
 
-def init_distributed():
-    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device)."""
+def init_distributed(backend: str = "nccl"):
+    """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device).
+    backend "nccl" is RCCL over xGMI (production); "gloo" lets several ranks share one GPU (tests: the collectives are
+    staged through the host, the kernels and the launcher logic are the same)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("the MI355X `nerf` package needs a ROCm device")
+    if backend == "gloo":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=dev)      # nccl == RCCL on ROCm
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=dev)      # nccl == RCCL on ROCm
+        else:
+            torch.distributed.init_process_group(backend=backend)
     return rank, world, dev
+
+
+class FrameStager:
+    """Host -> device staging of the one frame a training step needs (image, pose, expression) through a small pinned double
+    buffer.  The dataset itself stays in pageable memory (a few thousand 512x512x3 float frames would otherwise be ~15 GB
+    of page-locked memory per rank); the copy of step i+1 overlaps the kernels of step i."""
+
+    def __init__(self, images, poses, expressions, device, slots: int = 2):
+        self.images, self.poses, self.expressions, self.device = images, poses, expressions, device
+        mk = lambda t: torch.empty(t.shape[1:], dtype=t.dtype).pin_memory()
+        self.slots = [(mk(images), mk(poses), mk(expressions), torch.cuda.Event()) for _ in range(slots)]
+        self.k = 0
+
+    def fetch(self, idx: int):
+        img, pose, expr, ev = self.slots[self.k]
+        self.k = (self.k + 1) % len(self.slots)
+        ev.synchronize()                                   # the transfer that last used this slot (2 steps ago) has landed
+        img.copy_(self.images[idx])
+        pose.copy_(self.poses[idx])
+        expr.copy_(self.expressions[idx])
+        out = (img.to(self.device, non_blocking=True), pose.to(self.device, non_blocking=True),
+               expr.to(self.device, non_blocking=True))
+        ev.record(torch.cuda.current_stream(self.device))
+        return out
 
 
 def load_config(path: str):

@@ -36,16 +36,18 @@ def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", type=str, required=True, help="Path to (.yml) config file.")
     ap.add_argument("--load-checkpoint", type=str, default="", help="Path to load saved checkpoint from.")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"),
+                    help="torch.distributed backend: nccl = RCCL over xGMI (default); gloo = several ranks on one GPU (tests)")
     args = ap.parse_args(argv)
-    rank, world, dev = CM.init_distributed()
+    rank, world, dev = CM.init_distributed(args.backend)
     cfg = CM.load_config(args.config)
     images, poses, render_poses, hwf, i_split, expressions, _, bboxs = nerf.load_flame_data(
         cfg.dataset.basedir, half_res=cfg.dataset.half_res, testskip=cfg.dataset.testskip)
     i_train, i_val, i_test = i_split
     H, W, intrinsics = int(hwf[0]), int(hwf[1]), hwf[2]
-    # frames stay on the host (the reference keeps the whole sequence in one CPU tensor, TR:61-72); pinned so that the one
-    # frame a step needs crosses PCIe asynchronously, overlapped with the previous step's kernels
-    images, poses, expressions = images.pin_memory(), poses.pin_memory(), expressions.pin_memory()
+    # frames stay on the host in pageable memory (the reference keeps the whole sequence in one CPU tensor, TR:61-72); the one
+    # frame a step needs crosses PCIe asynchronously through a pinned double buffer, overlapped with the previous step's kernels
+    stager = CM.FrameStager(images, poses[:, :3, :4].contiguous(), expressions, dev)
     seed = cfg.experiment.randomseed
     np.random.seed(D.rank_seed(seed))
     torch.manual_seed(seed)                                   # identical model init everywhere (also broadcast below)
@@ -72,6 +74,8 @@ def main(argv=None):
         optimizer.load_state_dict(ck["optimizer_state_dict"])
         start_iter = int(ck["iter"])
     D.broadcast_parameters(trainable)
+    # from here on every rank draws its OWN rays and noise: the shared seed above served the identical initialisation only
+    torch.manual_seed(D.rank_seed(seed))
     reducer = D.GradientAllReducer(trainable)
     maps = [torch.from_numpy(m).to(dev) for m in importance_maps(bboxs[i_train].numpy(), H, W)]
     coords = torch.stack(nerf.meshgrid_xy(torch.arange(H, device=dev), torch.arange(W, device=dev)), dim=-1).reshape(-1, 2)
@@ -85,15 +89,16 @@ def main(argv=None):
         model_f.train()
     n_rays = cfg.nerf.train.num_random_rays
     t0 = time.time()
+    first_draw = None
     for i in range(start_iter, cfg.experiment.train_iters):
         k = int(np.random.randint(len(i_train)))              # one frame per rank per step (TR:289)
         img_idx = int(i_train[k])
-        target_img = images[img_idx].to(dev, non_blocking=True)
-        pose = poses[img_idx, :3, :4].to(dev, non_blocking=True)
-        expr = expressions[img_idx].to(dev, non_blocking=True)
+        target_img, pose, expr = stager.fetch(img_idx)
         latent = latent_codes[k]
         ro, rd = nerf.get_ray_bundle(H, W, intrinsics, pose)
         sel = coords[torch.multinomial(maps[k], n_rays, replacement=False)]
+        if first_draw is None:
+            first_draw = (img_idx, sel[:8].clone())
         ro, rd = ro[sel[:, 0], sel[:, 1], :], rd[sel[:, 0], sel[:, 1], :]
         target = target_img[sel[:, 0], sel[:, 1], :]
         bg = background[sel[:, 0], sel[:, 1], :] if background is not None else None
@@ -103,7 +108,7 @@ def main(argv=None):
         loss = torch.nn.functional.mse_loss(rgb_c[..., :3], target[..., :3])
         if rgb_f is not None:
             loss = loss + torch.nn.functional.mse_loss(rgb_f[..., :3], target[..., :3])
-        psnr = nerf.mse2psnr(loss.item())
+        mse = loss.detach()                                    # read back (a host sync) only on the iterations that log or save
         loss = loss + 10 * (torch.norm(latent) * 0.0005)       # TR:375-387
         loss.backward()
         reducer.reduce()
@@ -113,14 +118,33 @@ def main(argv=None):
         for g in optimizer.param_groups:
             g["lr"] = lr_new
         if rank == 0 and (i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1):
-            print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {psnr:.4f} ({(time.time() - t0):.1f} s, {world} GPU)")
+            print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {nerf.mse2psnr(mse.item()):.4f} "
+                  f"({(time.time() - t0):.1f} s, {world} GPU)")
         if rank == 0 and (i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1):
+            psnr = nerf.mse2psnr(mse.item())
             torch.save({"iter": i, "model_coarse_state_dict": model_c.state_dict(),
                         "model_fine_state_dict": None if model_f is None else model_f.state_dict(),
                         "optimizer_state_dict": optimizer.state_dict(), "loss": loss, "psnr": psnr,
                         "background": None if background is None else background.data, "latent_codes": latent_codes.data},
                        os.path.join(logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
     if torch.distributed.is_initialized():
+        # replica consistency: after identical Adam steps on averaged gradients every rank must hold the same parameters, and
+        # the ranks must have drawn different frames / rays (one checksum + the first draw per rank, gathered once at the end)
+        import json
+        chk = torch.stack([p.detach().double().sum() for p in trainable]).sum().reshape(1)
+        draw = torch.cat((torch.tensor([float(first_draw[0])], device=dev), first_draw[1].reshape(-1).float())).double()
+        both = torch.cat((chk, draw))
+        gathered = [torch.zeros_like(both) for _ in range(world)]
+        torch.distributed.all_gather(gathered, both)
+        if rank == 0:
+            sums = [float(g[0]) for g in gathered]
+            draws = [[int(v) for v in g[1:].tolist()] for g in gathered]
+            report = {"world": world, "iters": int(cfg.experiment.train_iters - start_iter), "parameter_checksums": sums,
+                      "identical_parameters": all(v == sums[0] for v in sums), "first_draw_per_rank": draws,
+                      "distinct_draws": len({tuple(d) for d in draws}) == world}
+            with open(os.path.join(logdir, "dp_consistency.json"), "w") as f:
+                json.dump(report, f)
+            print(f"[DP] {world} ranks: identical parameters = {report['identical_parameters']}, distinct ray draws = {report['distinct_draws']}")
         torch.distributed.barrier()
     return logdir
 

@@ -37,65 +37,102 @@ def gather_frame_order(n_frames: int, world: int) -> List[tuple]:
     return [(i % world, i // world) for i in range(n_frames)]
 
 
-def _flat_params(tensors: Iterable[torch.Tensor]) -> List[torch.Tensor]:
-    return [t for t in tensors]
-
-
 class GradientAllReducer:
-    """Flat-buffer gradient averaging for [model_coarse, model_fine, latent table].
+    """Flat-buffer gradient averaging for [model_coarse, model_fine, latent table]: per step ONE multi-tensor copy into a
+    persistent flat buffer, ONE all-reduce, one scale, one multi-tensor copy back -- no per-parameter kernels and no
+    host/device synchronisation.
 
-    Parameters whose .grad is None (layers_dir.3, Quirk Q3; latent rows are dense in the table's grad) contribute
-    zeros, so every rank reduces a buffer of identical layout.  After `reduce()` every parameter that had a gradient
-    on ANY rank has the averaged gradient; parameters that had none anywhere keep grad=None."""
+    Which parameters carry a gradient is a static property of the path (only `layers_dir.3`, Quirk Q3, never does): the
+    pattern is taken from `p.grad is None` on the host at the first step and agreed on once across ranks (union); later
+    steps assert it still holds.  Parameters without a gradient anywhere keep grad=None; a parameter of the union whose
+    local gradient is None contributes zeros.  The fused backward returns a model's gradients as views of one flat tensor
+    (ops.paper_mlp_bwd), so neighbouring views are coalesced into single runs: the copies move a handful of large spans
+    (coarse | fine | latent table), not 50 small tensors."""
 
     def __init__(self, params: Sequence[torch.Tensor], group=None):
         self.params = list(params)
         self.group = group
         self.sizes = [p.numel() for p in self.params]
-        self.total = sum(self.sizes)
+        self.mask = None               # agreed has-gradient pattern (list of bool), fixed after the first reduce()
         self._buf = None
+        self._views = None
 
-    def _buffer(self, device):
-        # one extra slot per parameter carries "had a gradient" so that grad=None survives when it is None everywhere
-        n = self.total + len(self.params)
-        if self._buf is None or self._buf.device != device or self._buf.numel() != n:
-            self._buf = torch.zeros(n, dtype=torch.float32, device=device)
-        return self._buf
+    def reset(self) -> None:
+        """Forget the agreed gradient pattern (after (un)freezing parameters).  Collective: call on every rank."""
+        self.mask, self._buf, self._views = None, None, None
+
+    def _negotiate(self, device) -> None:
+        local = [p.grad is not None for p in self.params]
+        flags = torch.tensor([1.0 if f else 0.0 for f in local], dtype=torch.float32, device=device)
+        dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.group)
+        self.mask = [v > 0 for v in flags.tolist()]                       # the only host sync, once per run
+        total = sum(n for n, m in zip(self.sizes, self.mask) if m)
+        self._buf = torch.zeros(total, dtype=torch.float32, device=device)
+        self._views, off = [], 0
+        for p, n, m in zip(self.params, self.sizes, self.mask):
+            self._views.append(self._buf[off:off + n].view_as(p) if m else None)
+            off += n if m else 0
+
+    @staticmethod
+    def _runs(grads, views):
+        """Coalesce (gradient, buffer view) pairs whose gradients are adjacent views of one storage into flat spans."""
+        out_g, out_v = [], []
+        i, n = 0, len(grads)
+        while i < n:
+            g, v = grads[i], views[i]
+            j, span = i + 1, g.numel()
+            if g.is_contiguous():
+                base, esz = g.untyped_storage().data_ptr(), g.element_size()
+                while (j < n and grads[j].is_contiguous() and grads[j].untyped_storage().data_ptr() == base
+                       and grads[j].storage_offset() == g.storage_offset() + span):
+                    span += grads[j].numel()
+                    j += 1
+            if j - i > 1:
+                out_g.append(torch.as_strided(g, (span,), (1,)))
+                out_v.append(torch.as_strided(v, (span,), (1,)))
+            else:
+                out_g.append(g)
+                out_v.append(v)
+            i = j
+        return out_g, out_v
 
     def reduce(self) -> None:
         _, world = world_info()
         if world == 1:
             return
         device = self.params[0].device
-        buf = self._buffer(device)
-        buf.zero_()
-        off = 0
-        for i, (p, n) in enumerate(zip(self.params, self.sizes)):
-            if p.grad is not None:
-                buf[off:off + n].copy_(p.grad.reshape(-1))
-                buf[self.total + i] = 1.0
-            off += n
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group)
-        flags = buf[self.total:].tolist()
-        off = 0
-        for i, (p, n) in enumerate(zip(self.params, self.sizes)):
-            if flags[i] > 0:
-                g = (buf[off:off + n] / world).view_as(p)
-                if p.grad is None:
-                    p.grad = g.clone()
-                else:
-                    p.grad.copy_(g)
-            off += n
+        if self.mask is None:
+            self._negotiate(device)
+        grads, views = [], []
+        for p, v, m in zip(self.params, self._views, self.mask):
+            if not m:
+                if p.grad is not None:
+                    raise RuntimeError("GradientAllReducer: a parameter gained a gradient after the first step; call reset() on every rank")
+                continue
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+            grads.append(p.grad)
+            views.append(v)
+        with torch.no_grad():
+            run_g, run_v = self._runs(grads, views)
+            torch._foreach_copy_(run_v, run_g)
+            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+            self._buf.mul_(1.0 / world)
+            torch._foreach_copy_(run_g, run_v)
 
 
 def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group=None) -> None:
-    """Identical initial state on every rank (model weights, latent table)."""
+    """Identical initial state on every rank (model weights, latent table).  c10d collectives write into the storage
+    without touching the autograd version counter, and the packed-weight caches (ops.PaperWeights) are keyed on
+    (data_ptr, version): so the counters are bumped explicitly afterwards (one multi-tensor `x *= 1`), which invalidates
+    every cached weight image that was packed before the broadcast."""
     _, world = world_info()
     if world == 1:
         return
     with torch.no_grad():
         for p in params:
-            dist.broadcast(p.data, src=src, group=group)
+            dist.broadcast(p.detach(), src=src, group=group)
+        torch._foreach_mul_([p.detach() for p in params], 1.0)
 
 
 def rank_seed(base_seed: int) -> int:

@@ -23,9 +23,10 @@ PAPER_KEYS = (
 )
 
 
-# Arithmetic of the MLP forward GEMMs: "f32" = exact-f32 MFMA; "bf16x3" = split-bf16, three bf16 MFMAs per product with
-# f32 accumulation (~2^-16 relative per layer, 3x faster).  It applies to inference and to the forward of a training step
-# (which then also saves its f32 activations); the backward always runs the exact-f32 kernels.
+# Arithmetic of the MLP GEMMs: "f32" = exact-f32 MFMA (the library default and the arithmetic of the reference);
+# "bf16x3" = split-bf16, three bf16 MFMAs per product with f32 accumulation (~2^-16 relative per product, 3x faster).
+# The switch applies to inference AND to a training step: under "bf16x3" the training forward, the dX chain and the
+# weight-gradient GEMMs all run on the split-bf16 kernels (paper_mlp_bwd(..., exact_dw=True) keeps the dW GEMMs exact).
 _VALID_PRECISIONS = ("f32", "bf16x3")
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
 
@@ -131,6 +132,12 @@ class PaperWeights:
         self.packed_bt = None           # transposed (hi, lo) bf16 stream for the split-bf16 backward chain
         self._versions_bt = None
 
+    def invalidate(self) -> None:
+        """Drop every cached image.  The caches follow in-place updates through the parameters' version counters
+        (optimizer.step(), load_state_dict(), copy_ under no_grad); writes that bypass the counter -- through `p.data`, or by
+        a collective -- are NOT seen: call this (or model.hip_weights().invalidate()) after such a write."""
+        self._versions = self._versions_t = self._versions_b = self._versions_bt = None
+
     def get_t(self) -> torch.Tensor:
         """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
         sig = self._signature()
@@ -224,7 +231,8 @@ def paper_mlp_fwd_bf16(packed_b, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
 
 def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):
     """Training forward: returns (raw, (saved,)) where `saved` holds every layer output for the backward.
-    packed_b given -> the forward runs on the split-bf16 kernel (the backward is always exact f32)."""
+    packed_b given -> the forward runs on the split-bf16 kernel and `saved` additionally carries its ReLU bit masks; the
+    matching backward is paper_mlp_bwd(..., split=True)."""
     dev = H.require_device(packed, cond, ro, rd, z, rd_view)
     n_rays, n_samples = z.shape
     lib = H.lib()

@@ -32,6 +32,9 @@ CASES = {
     "train_rand_64_64": dict(frame=17, n_rays=24, n_coarse=64, n_fine=64, stochastic=True, noise_std=0.1),
     "ragged_5_7": dict(frame=5, n_rays=7, n_coarse=5, n_fine=7, stochastic=True, noise_std=0.0),
     "coarse_only": dict(frame=8, n_rays=9, n_coarse=16, n_fine=0, stochastic=False, noise_std=0.0),
+    # "soft" family: SURVEY §8(d)'s density head (fc_alpha x40, bias 0.5) -- the tight per-stage tolerances apply to these
+    "soft_eval_det_64_128": dict(frame=3, n_rays=64, n_coarse=64, n_fine=128, stochastic=False, noise_std=0.0, boost="survey"),
+    "soft_train_rand_64_64": dict(frame=17, n_rays=48, n_coarse=64, n_fine=64, stochastic=True, noise_std=0.1, boost="survey"),
 }
 
 
@@ -48,8 +51,9 @@ def build_case(name, dtype=torch.float32):
                  noise_c_unit=noise_c, noise_f_unit=noise_f)
     else:
         c.update(t_rand=None, u=None, noise_c=None, noise_f=None)
-    c["p_coarse"] = O.init_paper_params(0, dtype)
-    c["p_fine"] = O.init_paper_params(1, dtype)
+    boost = c.pop("boost", True)
+    c["p_coarse"] = O.init_paper_params(0, dtype, boost=boost)
+    c["p_fine"] = O.init_paper_params(1, dtype, boost=boost)
     return c
 
 

@@ -159,7 +159,8 @@ def main():
         make_pe_pdf(ref)
         return
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
-    for name in C.CASES:
+    only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None     # `cases NAME...`: only these 7-tuple fixtures
+    for name in (only or C.CASES):
         c = C.build_case(name)
         out_ref, _ = run_reference(ref, c)
         st = {}
@@ -173,6 +174,8 @@ def main():
             print(f"[{name}] {n}: exact={exact} max|d|={float((a - b).abs().max()):.3e}")
             blob[n] = a.numpy()
         np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **blob)
+    if only:
+        return
 
     # ablation path (Quirk Q7, the call pattern of the shipped eval script): 48 rays in 3 chunks of 16, directions for the
     # ENCODING taken from chunk 0 of another pose's rays for every chunk (T:81-82)

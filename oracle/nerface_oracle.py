@@ -86,17 +86,23 @@ PAPER_SHAPES = {
 }
 
 
-def init_paper_params(seed: int, dtype=torch.float32, boost: bool = True) -> Dict[str, torch.Tensor]:
-    """Seeded synthetic weights with nn.Linear-style uniform(-1/sqrt(in), 1/sqrt(in)) init and the
-    density boost in the spirit of SURVEY §8(d) (fc_alpha.weight*1000, fc_alpha.bias=5, fc_rgb.weight*10;
-    background transmittance then spans ~0.4..0.94 with both zero and positive densities along a ray).  (Own generator; not meant to equal torch's default init stream.)"""
+def init_paper_params(seed: int, dtype=torch.float32, boost=True) -> Dict[str, torch.Tensor]:
+    """Seeded synthetic weights with nn.Linear-style uniform(-1/sqrt(in), 1/sqrt(in)) init and a density boost.
+    boost=True ("hard" family): fc_alpha.weight*1000, fc_alpha.bias=5, fc_rgb.weight*10 -- sharp surfaces, d sigma/dz ~ 1e5,
+    a stress test of the resampling sensitivity.  boost="survey" ("soft" family): SURVEY §8(d)'s head, fc_alpha.weight*40,
+    fc_alpha.bias=0.5, fc_rgb.weight*10 -- densities of a few units, on which the tight per-stage tolerances of §8(d)
+    (rgb 2e-5, weights 1e-5, z_samples 1e-5) are enforced.  (Own generator; not meant to equal torch's default init stream.)"""
     g = torch.Generator().manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
     for k, shp in PAPER_SHAPES.items():
         bound = 1.0 / math.sqrt(shp[1])
         out[k] = ((torch.rand(shp, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
         out[k.replace("weight", "bias")] = ((torch.rand(shp[0], generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
-    if boost:
+    if boost == "survey":
+        out["fc_alpha.weight"] = out["fc_alpha.weight"] * 40.0
+        out["fc_alpha.bias"] = torch.full_like(out["fc_alpha.bias"], 0.5)
+        out["fc_rgb.weight"] = out["fc_rgb.weight"] * 10.0
+    elif boost:
         out["fc_alpha.weight"] = out["fc_alpha.weight"] * 1000.0
         out["fc_alpha.bias"] = torch.full_like(out["fc_alpha.bias"], 5.0)
         out["fc_rgb.weight"] = out["fc_rgb.weight"] * 10.0
@@ -219,10 +225,11 @@ def encode_points(ro, rd, z, near: float, far: float, rd_view=None) -> torch.Ten
 # A3  stratified coarse sampler                                              (T:50-78)
 # --------------------------------------------------------------------------------------
 
-def coarse_z(n_rays: int, near: float, far: float, n_coarse: int, t_rand: Optional[torch.Tensor], dtype=torch.float32):
-    t = torch.linspace(0.0, 1.0, n_coarse, dtype=dtype)
-    nr = torch.full((n_rays, 1), near, dtype=dtype)
-    fr = torch.full((n_rays, 1), far, dtype=dtype)
+def coarse_z(n_rays: int, near: float, far: float, n_coarse: int, t_rand: Optional[torch.Tensor], dtype=torch.float32,
+             device=None):
+    t = torch.linspace(0.0, 1.0, n_coarse, dtype=dtype, device=device)
+    nr = torch.full((n_rays, 1), near, dtype=dtype, device=device)
+    fr = torch.full((n_rays, 1), far, dtype=dtype, device=device)
     z = nr * (1.0 - t) + fr * t
     if t_rand is not None:                                      # perturb=True (T:69-76)
         mids = 0.5 * (z[:, 1:] + z[:, :-1])
@@ -279,7 +286,7 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
     cdf = torch.cumsum(pdf, dim=-1)
     cdf = torch.cat((torch.zeros_like(cdf[:, :1]), cdf), dim=-1)
     if u is None:
-        u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=w.dtype).expand(cdf.shape[0], n_samples)
+        u = torch.linspace(0.0, 1.0, steps=n_samples, dtype=w.dtype, device=w.device).expand(cdf.shape[0], n_samples)
     u = u.contiguous()
     idx = torch.searchsorted(cdf.contiguous(), u, right=True)
     if table is not None:
@@ -306,7 +313,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
     R = ro.shape[0]
     st = stages if stages is not None else {}
     paper_mlp = mlp if mlp is not None else globals()["paper_mlp"]          # model family (default: the paper model)
-    z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype)
+    z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype, device=ro.device)
     raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far, rd_view), expr, latent).reshape(R, n_coarse, 4).clone()
     st["raw_c_mlp"] = raw.clone()
     if bg is not None:
