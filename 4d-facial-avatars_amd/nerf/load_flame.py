@@ -21,7 +21,19 @@ def _read_png(path: str) -> np.ndarray:
 
 
 def _area_resize(img: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
-    """Box-filter (INTER_AREA-like) resize of a float image (H, W, C)."""
+    """cv2.resize(img, (out_w, out_h), interpolation=cv2.INTER_AREA) of a float32 image (H, W, C), as the reference calls it
+    (LF:150-152, LF:171-175).  For an integer shrink factor -- half_res, the only resize a shipped config uses -- OpenCV
+    averages each source block with one float accumulator in row-major order and multiplies by 1/area; that order is kept,
+    so the pixels are the ones cv2 produces.  Other factors (the 25x25 `debug` thumbnails) fall back to PIL's box filter,
+    which weights partially covered pixels like INTER_AREA but rounds differently."""
+    h, w = img.shape[:2]
+    if out_h > 0 and out_w > 0 and h % out_h == 0 and w % out_w == 0:
+        fy, fx = h // out_h, w // out_w
+        acc = np.zeros((out_h, out_w) + img.shape[2:], dtype=np.float32)
+        for sy in range(fy):
+            for sx in range(fx):
+                acc = (acc + img[sy::fy, sx::fx]).astype(np.float32)
+        return (acc * np.float32(1.0 / (fx * fy))).astype(np.float32)
     from PIL import Image
     chans = [np.asarray(Image.fromarray(img[..., c].astype(np.float32), mode="F").resize((out_w, out_h), Image.BOX))
              for c in range(img.shape[-1])]

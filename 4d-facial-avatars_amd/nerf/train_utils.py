@@ -226,8 +226,10 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
 
 
 class GaussianSmoothing(torch.nn.Module):
-    """T:379-...: separable Gaussian blur used only by commented-out experiments of the trainer.  Kept so that
-    `from nerf import GaussianSmoothing` succeeds (train_transformed_rays.py:19-21)."""
+    """T:379-442: depthwise Gaussian blur used only by commented-out experiments of the trainer.  Kept so that
+    `from nerf import GaussianSmoothing` succeeds (train_transformed_rays.py:19-21), with the reference's own kernel
+    formula exp(-((x - mean) / (2 sigma))^2) (T:409-410 -- not the textbook exp(-x^2 / (2 sigma^2)); a drop-in keeps it)
+    and its fixed padding of 5 (T:442)."""
 
     def __init__(self, channels, kernel_size, sigma, dim=2):
         super().__init__()
@@ -241,9 +243,10 @@ class GaussianSmoothing(torch.nn.Module):
         grids = torch.meshgrid([torch.arange(s, dtype=torch.float32) for s in kernel_size], indexing="ij")
         for size, std, mgrid in zip(kernel_size, sigma, grids):
             mean = (size - 1) / 2
-            kernel = kernel * (1 / (std * math.sqrt(2 * math.pi)) * torch.exp(-(((mgrid - mean) / std) ** 2) / 2))
+            kernel = kernel * (1 / (std * math.sqrt(2 * math.pi)) * torch.exp(-((mgrid - mean) / (2 * std)) ** 2))
         kernel = kernel / torch.sum(kernel)
-        kernel = kernel.view(1, 1, *kernel.size()).repeat(channels, *[1] * (kernel.dim() - 1))
+        kernel = kernel.view(1, 1, *kernel.size())
+        kernel = kernel.repeat(channels, *[1] * (kernel.dim() - 1))
         self.register_buffer("weight", kernel)
         self.groups = channels
         self.conv = {1: torch.nn.functional.conv1d, 2: torch.nn.functional.conv2d, 3: torch.nn.functional.conv3d}[dim]

@@ -104,6 +104,54 @@ def make_lcode_grads(ref):
     print("lcode grad fixture: loss", float(loss), "latent |g|", float(latent.grad.norm()))
 
 
+def eval_post_inputs():
+    """Seeded inputs of the eval post-processing fixture: an out-of-range colour image, a disparity-like map and weights
+    (some above the 0.22 threshold of EV:112), 48x48 and 64x64."""
+    out = {}
+    for n, seed in ((48, 8), (64, 9)):
+        g = torch.Generator().manual_seed(seed)
+        out[n] = (torch.rand((n, n, 3), generator=g) * 1.4 - 0.2, torch.rand((n, n), generator=g) * 0.5 + 1.0,
+                  torch.rand((n, n), generator=g) * 0.5)
+    return out
+
+
+def make_eval_post():
+    """cast_to_image (EV:184-190) and torch_normal_map(..., clean=True) (EV:84-119) of the UNMODIFIED eval script; the normal
+    map is stored as the script hands it to the image writer: `.cpu().numpy().astype('uint8')` (EV:471)."""
+    ev = RI.import_reference_eval()
+    blob = {}
+    for n, (rgb, disp, w) in eval_post_inputs().items():
+        blob[f"rgb_u8_{n}"] = ev.cast_to_image(rgb, "blender")
+        blob[f"normals_u8_{n}"] = ev.torch_normal_map(disp.clone(), O.INTRINSICS, w, clean=True).cpu().numpy().astype("uint8")
+        blob[f"normals_plain_u8_{n}"] = ev.torch_normal_map(disp.clone(), O.INTRINSICS, None, clean=True).cpu().numpy().astype("uint8")
+        assert np.array_equal(blob[f"rgb_u8_{n}"], O.cast_to_u8(rgb).numpy())
+        assert np.array_equal(blob[f"normals_u8_{n}"], O.normal_map(disp, O.INTRINSICS, w).numpy())
+    np.savez_compressed(os.path.join(OUT, "eval_post.npz"), **blob)
+    print("eval_post fixture written (oracle restatement == reference, bit exact)")
+
+
+def make_load_flame():
+    """load_flame_data (LF:40-211) of the UNMODIFIED reference on the synthetic on-disk dataset of tools/make_synthetic_dataset.py
+    (regenerated from its seed by the test), with imageio/cv2 backed as described in ref_import.flame_loader_io."""
+    import tempfile
+    sys.path.insert(0, os.path.join(os.path.dirname(OUT), "..", "tools"))
+    import make_synthetic_dataset as MS
+    blob = {}
+    with tempfile.TemporaryDirectory() as tmp, RI.flame_loader_io() as lf:
+        MS.write(tmp, size=32, n_train=6, n_val=4, n_test=5, seed=3)
+        for tag, kw in (("full", dict()), ("half", dict(half_res=True)), ("skip2", dict(testskip=2)), ("test", dict(test=True, half_res=True))):
+            imgs, poses, render_poses, hwf, i_split, expr, frontal, bboxs = lf.load_flame_data(tmp, **kw)
+            assert frontal is None
+            blob.update({f"{tag}_imgs": imgs.numpy(), f"{tag}_poses": poses.numpy(), f"{tag}_render_poses": render_poses.numpy(),
+                         f"{tag}_hw": np.array(hwf[:2]), f"{tag}_intrinsics": np.asarray(hwf[2], dtype=np.float64),
+                         f"{tag}_expr": expr.numpy(), f"{tag}_bboxs": bboxs.numpy()})
+            for k, ix in enumerate(i_split):
+                blob[f"{tag}_split{k}"] = np.asarray(ix)
+            print(f"load_flame[{tag}]: imgs {tuple(imgs.shape)} {imgs.dtype}, poses {tuple(poses.shape)}, render_poses {render_poses.dtype}, "
+                  f"bboxs {bboxs.dtype} {bboxs[0].tolist()}, H W {hwf[:2]}")
+    np.savez_compressed(os.path.join(OUT, "load_flame.npz"), **blob)
+
+
 def make_pe_pdf(ref):
     """positional encoding + sample_pdf_2 (H:344-387) incl. edge cases.  The reference returns only the samples; the CDF
     table and the searchsorted indices stored next to them come from the oracle restatement AFTER it reproduced the
@@ -157,6 +205,12 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "pe_pdf":
         make_pe_pdf(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_post":
+        make_eval_post()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "load_flame":
+        make_load_flame()
         return
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None     # `cases NAME...`: only these 7-tuple fixtures
@@ -249,6 +303,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "ray_bundle.npz"), rd=rd.numpy(), ro=ro.numpy(), rd_scalar=rd_s.numpy())
 
     make_pe_pdf(ref)
+    make_eval_post()
+    make_load_flame()
 
     # tiny_nerf (BASELINE config 1): 64x64, 32 samples, 3-layer 128-wide MLP, coarse only
     TN = RI.import_reference_tiny()

@@ -421,8 +421,9 @@ def synthetic_image(height: int, width: int, seed: int, dtype=torch.float32) -> 
 
 
 # --------------------------------------------------------------------------------------
-# eval post-processing (reference eval_transformed_rays.py:84-119, 184-190).  NOT pinned against the live reference:
-# the eval script cannot be imported without torchvision/imageio; restated from the source.
+# eval post-processing (reference eval_transformed_rays.py:84-119, 184-190).  Pinned: oracle/make_golden.py imports the
+# unmodified eval script (torchvision/imageio stubbed, oracle/ref_import.py) and stores its outputs in
+# tests/golden/eval_post.npz; this restatement reproduces them bit for bit (tests/test_oracle_golden.py).
 # --------------------------------------------------------------------------------------
 
 def cast_to_u8(img: torch.Tensor) -> torch.Tensor:

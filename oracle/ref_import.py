@@ -52,10 +52,7 @@ def import_reference_tiny():
     with the reference `nerf` package temporarily visible under its public name."""
     if "_ref_tiny_nerf" in sys.modules:
         return sys.modules["_ref_tiny_nerf"]
-    import_reference()
-    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "nerf" or k.startswith("nerf.")}
-    for k in [k for k in sys.modules if k.startswith("_ref_nerf")]:
-        sys.modules[k[len("_ref_"):]] = sys.modules[k]
+    saved = _expose_reference_nerf()
     sys.path.insert(0, REF_ROOT)
     try:
         import matplotlib
@@ -63,11 +60,111 @@ def import_reference_tiny():
         mod = importlib.import_module("tiny_nerf")
     finally:
         sys.path.remove(REF_ROOT)
-        for k in [k for k in sys.modules if k == "nerf" or k.startswith("nerf.")]:
-            del sys.modules[k]
-        sys.modules.update(saved)
+        _hide_reference_nerf(saved)
     sys.modules["_ref_tiny_nerf"] = sys.modules.pop("tiny_nerf")
     return mod
+
+
+def _expose_reference_nerf():
+    """Make the reference `nerf` package importable under its public name; returns what to restore afterwards."""
+    import_reference()
+    saved = {k: sys.modules.pop(k) for k in list(sys.modules) if k == "nerf" or k.startswith("nerf.")}
+    for k in [k for k in sys.modules if k.startswith("_ref_nerf")]:
+        sys.modules[k[len("_ref_"):]] = sys.modules[k]
+    return saved
+
+
+def _hide_reference_nerf(saved):
+    for k in [k for k in sys.modules if k == "nerf" or k.startswith("nerf.")]:
+        del sys.modules[k]
+    sys.modules.update(saved)
+
+
+def _torchvision_stub():
+    """torchvision is not installed here.  The eval script uses exactly one thing from it, transforms.ToPILImage() on a
+    float (3, H, W) tensor (EV:184-190); torchvision (pinned 0.6.0 in nerf.yml:75) documents and implements that as
+    `pic.mul(255).byte()` -> HWC numpy -> PIL.Image.fromarray.  The stub restates just that."""
+    import numpy as np
+    from PIL import Image
+    tv = types.ModuleType("torchvision")
+    tr = types.ModuleType("torchvision.transforms")
+
+    class ToPILImage:
+        def __call__(self, pic):
+            if pic.is_floating_point():
+                pic = pic.mul(255).byte()
+            return Image.fromarray(np.transpose(pic.cpu().numpy(), (1, 2, 0)))
+
+    tr.ToPILImage = ToPILImage
+    tv.transforms = tr
+    return tv, tr
+
+
+def import_reference_eval():
+    """The reference's eval_transformed_rays.py script module (for torch_normal_map EV:84-119 and cast_to_image EV:184-190),
+    imported unmodified as ``_ref_eval`` (its `main()` sits behind `if __name__ == "__main__"`).  torchvision and imageio
+    are stubbed (see _torchvision_stub); matplotlib/tqdm/yaml are real."""
+    if "_ref_eval" in sys.modules:
+        return sys.modules["_ref_eval"]
+    saved = _expose_reference_nerf()
+    added = []
+    if "torchvision" not in sys.modules:
+        tv, tr = _torchvision_stub()
+        sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tr
+        added += ["torchvision", "torchvision.transforms"]
+    sys.path.insert(0, REF_ROOT)
+    try:
+        import matplotlib
+        matplotlib.use("Agg")
+        mod = importlib.import_module("eval_transformed_rays")
+    finally:
+        sys.path.remove(REF_ROOT)
+        _hide_reference_nerf(saved)
+        for k in added:
+            sys.modules.pop(k, None)
+    sys.modules["_ref_eval"] = sys.modules.pop("eval_transformed_rays")
+    return mod
+
+
+def cv2_area_resize(img, dsize):
+    """OpenCV is not installed here.  What load_flame.py:171-175 needs is cv2.resize(float32 HxWx3, dsize=(w, h),
+    interpolation=INTER_AREA) with an integer shrink factor: OpenCV (pinned opencv-python-headless 4.2.0.34, nerf.yml:93)
+    takes its resizeAreaFast_ path for that -- per output element a float accumulator summed over the source block in
+    row-major order, then `sum * (1/area)`.  3-channel float images do not take the SIMD shortcut (ResizeAreaFastVec_SIMD_32f
+    handles cn 1 and 4 only), so the scalar order is the order.  Restated here for the reference's `cv2` stub only."""
+    import numpy as np
+    h, w = img.shape[:2]
+    ow, oh = int(dsize[0]), int(dsize[1])
+    fy, fx = h // oh, w // ow
+    assert fy * oh == h and fx * ow == w, "restated for integer shrink factors only"
+    acc = np.zeros((oh, ow) + img.shape[2:], dtype=np.float32)
+    for sy in range(fy):
+        for sx in range(fx):
+            acc = (acc + img[sy::fy, sx::fx][:oh, :ow]).astype(np.float32)
+    return (acc * np.float32(1.0 / (fx * fy))).astype(np.float32)
+
+
+@contextlib.contextmanager
+def flame_loader_io():
+    """For the duration of the block the reference's nerf.load_flame sees an `imageio.imread` backed by PIL (imageio's own
+    PNG reader is Pillow) and a `cv2.resize` / `cv2.INTER_AREA` backed by cv2_area_resize.  Module attributes of the
+    stub modules are set and removed again; no reference file is touched."""
+    import numpy as np
+    from PIL import Image
+    import_reference()
+    lf = sys.modules["_ref_nerf.load_flame"]
+
+    def imread(path):
+        with Image.open(path) as im:
+            return np.asarray(im)
+
+    lf.imageio.imread = imread
+    lf.cv2.INTER_AREA = 3
+    lf.cv2.resize = lambda img, dsize=None, interpolation=None: cv2_area_resize(img, dsize)
+    try:
+        yield lf
+    finally:
+        del lf.imageio.imread, lf.cv2.INTER_AREA, lf.cv2.resize
 
 
 @contextlib.contextmanager

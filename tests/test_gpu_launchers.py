@@ -133,15 +133,21 @@ def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
         assert a.shape == (32, 32, 3) and a.std() > 0
 
 
-def test_eval_postprocess_matches_oracle(hip_lib, gpu):
+def test_eval_postprocess_against_reference_fixture(hip_lib, gpu):
+    """f3 on the device: k_eval_postprocess against the outputs of the UNMODIFIED eval script (cast_to_image EV:184-190,
+    torch_normal_map(clean=True) EV:84-119; tests/golden/eval_post.npz).  The uint8 colours are exact; the normal map is the
+    same IEEE op sequence, so it is compared exactly too, with a reported allowance of 1 LSB on at most 0.1 % of the values
+    for host compilers that contract a*b-c*d in torch's CPU cross product."""
     from nerf import ops
+    from oracle import make_golden as MG
     from oracle import nerface_oracle as O
-    g = torch.Generator().manual_seed(8)
-    rgb = torch.rand((48, 48, 3), generator=g) * 1.4 - 0.2
-    disp = torch.rand((48, 48), generator=g) * 0.5 + 1.0
-    w = torch.rand((48, 48), generator=g) * 0.5
-    u8, nrm = ops.eval_postprocess(rgb.to(gpu), disp.to(gpu), w.to(gpu), O.INTRINSICS)
-    assert torch.equal(u8.cpu(), O.cast_to_u8(rgb))
-    want = O.normal_map(disp, O.INTRINSICS, w)
-    d = (nrm.cpu().int() - want.int()).abs()
-    assert nrm.shape == (47, 47, 3) and int(d.max()) <= 1 and float((d == 0).float().mean()) > 0.99     # truncation at an ulp boundary
+    g = np.load(os.path.join(ROOT, "tests", "golden", "eval_post.npz"))
+    for n, (rgb, disp, w) in MG.eval_post_inputs().items():
+        u8, nrm = ops.eval_postprocess(rgb.to(gpu), disp.to(gpu), w.to(gpu), O.INTRINSICS)
+        assert np.array_equal(u8.cpu().numpy(), g[f"rgb_u8_{n}"])
+        d = np.abs(nrm.cpu().numpy().astype(int) - g[f"normals_u8_{n}"].astype(int))
+        print(f"normal map {n}x{n}: {int((d != 0).sum())} of {d.size} bytes differ (max {int(d.max())})")
+        assert nrm.shape == (n - 1, n - 1, 3) and int(d.max()) <= 1 and float((d != 0).mean()) <= 1e-3
+        _, plain = ops.eval_postprocess(rgb.to(gpu), disp.to(gpu), None, O.INTRINSICS)
+        d = np.abs(plain.cpu().numpy().astype(int) - g[f"normals_plain_u8_{n}"].astype(int))
+        assert int(d.max()) <= 1 and float((d != 0).mean()) <= 1e-3

@@ -2,6 +2,7 @@
 import ctypes
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -204,3 +205,52 @@ def test_public_api_names():
     a, b = nerf.meshgrid_xy(torch.arange(3), torch.arange(2))
     assert a.shape == (2, 3) and int(a[1, 2]) == 2 and int(b[1, 2]) == 1
     assert abs(nerf.mse2psnr(0.01) - 20.0) < 1e-9
+
+
+def _flame_dataset(tmp):
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_dataset as MS
+    return MS.write(str(tmp), size=32, n_train=6, n_val=4, n_test=5, seed=3)
+
+
+FLAME_MODES = (("full", dict()), ("half", dict(half_res=True)), ("skip2", dict(testskip=2)), ("test", dict(test=True, half_res=True)))
+
+
+def _check_flame(out, get):
+    imgs, poses, render_poses, hwf, i_split, expr, frontal, bboxs = out
+    assert frontal is None
+    assert imgs.dtype == torch.float32 and np.array_equal(imgs.numpy(), get("imgs"))
+    assert poses.dtype == torch.float32 and np.array_equal(poses.numpy(), get("poses"))
+    assert render_poses.numpy().dtype == get("render_poses").dtype and np.array_equal(render_poses.numpy(), get("render_poses"))
+    assert [int(hwf[0]), int(hwf[1])] == get("hw").tolist()
+    assert np.array_equal(np.asarray(hwf[2], dtype=np.float64), get("intrinsics"))
+    assert expr.dtype == torch.float32 and np.array_equal(expr.numpy(), get("expr"))
+    assert bboxs.dtype == torch.int32 and np.array_equal(bboxs.numpy(), get("bboxs"))
+    for k, ix in enumerate(i_split):
+        assert np.array_equal(np.asarray(ix), get(f"split{k}"))
+
+
+def test_load_flame_data_against_reference_fixture(tmp_path):
+    """f4: nerf.load_flame_data on the synthetic on-disk dataset equals, array for array and dtype for dtype, what the
+    reference's load_flame_data (LF:40-211) returned for the same files (tests/golden/load_flame.npz; full / half_res /
+    testskip / test-only), including the half_res images (cv2 INTER_AREA order, see nerf/load_flame.py:_area_resize)."""
+    import nerf
+    base = _flame_dataset(tmp_path)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "load_flame.npz"))
+    for tag, kw in FLAME_MODES:
+        _check_flame(nerf.load_flame_data(base, **kw), lambda k: g[f"{tag}_{k}"])
+
+
+def test_load_flame_data_against_live_reference(tmp_path):
+    from oracle import ref_import as RI
+    if not RI.reference_available():
+        pytest.skip("/root/reference only exists in the build container")
+    import nerf
+    base = _flame_dataset(tmp_path)
+    with RI.flame_loader_io() as lf:
+        for tag, kw in FLAME_MODES:
+            want = lf.load_flame_data(base, **kw)
+            blob = {"imgs": want[0].numpy(), "poses": want[1].numpy(), "render_poses": want[2].numpy(), "hw": np.array(want[3][:2]),
+                    "intrinsics": np.asarray(want[3][2], dtype=np.float64), "expr": want[5].numpy(), "bboxs": want[7].numpy()}
+            blob.update({f"split{k}": np.asarray(ix) for k, ix in enumerate(want[4])})
+            _check_flame(nerf.load_flame_data(base, **kw), lambda k: blob[k])

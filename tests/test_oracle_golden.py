@@ -137,3 +137,43 @@ def test_oracle_equals_live_reference():
         out_or = C.run_oracle(c)
         for a, b in zip(out_ref, out_or):
             assert (a is None and b is None) or torch.equal(a, b)
+
+
+def test_eval_postprocess_oracle_against_reference_fixture():
+    """f3: cast_to_image (EV:184-190) and torch_normal_map(clean=True) (EV:84-119): the restatement equals the outputs of the
+    unmodified eval script stored in tests/golden/eval_post.npz, bit for bit."""
+    from oracle import make_golden as MG
+    g = np.load(os.path.join(GOLD, "eval_post.npz"))
+    for n, (rgb, disp, w) in MG.eval_post_inputs().items():
+        assert np.array_equal(O.cast_to_u8(rgb).numpy(), g[f"rgb_u8_{n}"])
+        assert np.array_equal(O.normal_map(disp, O.INTRINSICS, w).numpy(), g[f"normals_u8_{n}"])
+        assert np.array_equal(O.normal_map(disp, O.INTRINSICS, None).numpy(), g[f"normals_plain_u8_{n}"])
+
+
+@pytest.mark.skipif(not RI.reference_available(), reason="/root/reference only exists in the build container")
+def test_eval_postprocess_fixture_equals_live_reference():
+    from oracle import make_golden as MG
+    ev = RI.import_reference_eval()
+    g = np.load(os.path.join(GOLD, "eval_post.npz"))
+    for n, (rgb, disp, w) in MG.eval_post_inputs().items():
+        assert np.array_equal(ev.cast_to_image(rgb, "blender"), g[f"rgb_u8_{n}"])
+        assert np.array_equal(ev.torch_normal_map(disp.clone(), O.INTRINSICS, w, clean=True).numpy().astype("uint8"), g[f"normals_u8_{n}"])
+
+
+def test_gaussian_smoothing_keeps_the_reference_formula():
+    """T:409-410: exp(-((x - mean) / (2 sigma))^2), normalised; checked against a direct evaluation and, in the build
+    container, the reference class itself."""
+    import math
+    import nerf
+    m = nerf.GaussianSmoothing(3, 11, 2.0)
+    x = torch.arange(11, dtype=torch.float32)
+    k1 = 1 / (2.0 * math.sqrt(2 * math.pi)) * torch.exp(-((x - 5.0) / 4.0) ** 2)
+    k2 = k1[:, None] * k1[None, :]
+    k2 = k2 / k2.sum()
+    assert m.weight.shape == (3, 1, 11, 11) and torch.allclose(m.weight[0, 0], k2, rtol=1e-6, atol=0)
+    img = torch.rand((1, 3, 20, 20), generator=torch.Generator().manual_seed(0))
+    assert m(img).shape == (1, 3, 20, 20)
+    if RI.reference_available():
+        ref = RI.import_reference()
+        r = ref.GaussianSmoothing(3, 11, 2.0)
+        assert torch.equal(r.weight, m.weight) and torch.equal(r(img), m(img))
