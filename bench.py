@@ -4,20 +4,28 @@
     python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
 
 One *step* = one full 512x512 frame through the product path exactly as eval_transformed_rays.py drives it:
-`get_ray_bundle` + `run_one_iter_of_nerf(mode="validation")` with the shipped validation settings
-(64 coarse + 128 fine samples, chunksize 65536, perturb: True, noise 0; paper model x2, expression + latent
-conditioning, background prior).  Inputs (pose, expression, latent code, background, weights) are resident in
-HBM before the timed region.  Metric (BASELINE.json): rays/sec = frames * 262144 / wall time, whole job.
+`get_ray_bundle` + `run_one_iter_of_nerf(mode="validation")` with the shipped validation settings (64 coarse + 128 fine
+samples, chunksize 65536, perturb: True, noise 0; paper model x2, expression + latent conditioning, background prior).
+Inputs (pose, expression, latent code, background, weights) are resident in HBM before the timed region.
+Metric (BASELINE.json): rays/sec = frames * 262144 / wall time, whole job.  The headline (`value`, `dtype` "f32") runs the
+exact-f32 MFMA kernels -- the reference's arithmetic (fp32 everywhere, nerf/models.py:236-261).
 
-N > 1: frames are sharded over ranks (eval is embarrassingly parallel); no data-path
-collective; each rank renders K frames of its own (weak scaling); time = max over ranks.
+N > 1: frames are sharded over ranks (eval is embarrassingly parallel); no data-path collective; each rank
+renders K frames of its own (weak scaling); time = max over ranks.
 
-Also reported on the same JSON line:
-  roofline     -- the dominant kernel (fused MLP forward, fine pass: 65536 rays x 192 samples per launch), timed
-                  live with HIP events on the launch stream; achieved = algorithmic FLOPs (1,100,032 per point,
-                  SURVEY §8(d)) / average launch duration, against the dense fp32-MFMA peak (157.3 TFLOP/s).
-  cpu_baseline -- the CPU oracle (port of the reference algorithm, oracle/nerface_oracle.py) timed on this
-                  box's host cores on a bounded sample of the same workload (rank 0, N=1 only).
+On the same JSON line (every BASELINE config that fits this box is timed by this one command):
+  roofline     -- the dominant kernel (fused MLP forward, fine pass: 65536 rays x 192 samples per launch), timed live with
+                  HIP events on the launch stream; achieved = algorithmic FLOPs (1,100,032 per point) / average
+                  launch duration, against the dense fp32-MFMA peak (157.3 TFLOP/s); `traffic` = HBM bytes per launch from
+                  rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes) run by this command on the same kernel.
+  split_bf16   -- the same K frames with nerf.set_mlp_precision("bf16x3") (three bf16 MFMAs per product, f32 accumulate):
+                  value, ms, its kernel's roofline against the dense bf16 peak, and its parity on the CPU sample.
+  train        -- configs[2]: 2048-ray training iterations (64+64, fwd + bwd + Adam) in both arithmetics, ms/iter, rays/s
+                  and the HBM roofline of the training MLP kernels (N>1: configs[4], data parallel with the flat all-reduce).
+  tiny         -- configs[0]: tiny_nerf 64x64x32 forward on the device next to the CPU oracle of the same image.
+  cpu_baseline -- the CPU oracle (port of the reference algorithm, oracle/nerface_oracle.py) timed on this box's host
+                  cores on a bounded sample of the same workload (rank 0, N=1 only); `reference_ratio` ties the port to the
+                  unmodified reference (both timed in the build container, profiles/r02_port_vs_reference_cpu.json).
 """
 from __future__ import annotations
 
@@ -125,7 +133,15 @@ def cpu_baseline(n_rays=12288):
         nerf.set_mlp_precision(keep)
     except Exception as e:                                    # the baseline number must not depend on this extra
         parity = {"error": repr(e)}
+    ratio = None
+    rpath = os.path.join(ROOT, "profiles", "r02_port_vs_reference_cpu.json")
+    if os.path.exists(rpath):
+        try:
+            ratio = json.load(open(rpath))
+        except Exception:
+            ratio = None
     return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+            "reference_ratio": ratio,
             "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s",
             "parity_on_sample": parity}
 
@@ -179,7 +195,7 @@ def train_roofline(args, model, dev, n_rays):
                     "per-kernel split and the PMC HBM bytes"}
 
 
-def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
+def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True):
     """configs[2] / configs[4]: the trainer's iteration (TR:289-400) on synthetic data -- full-frame ray bundle, 2048 random
     rays, run_one_iter_of_nerf(mode='train') with the shipped training settings (64+64, chunksize 2048, perturb, noise
     0.1), coarse+fine MSE + latent regulariser, backward, (N>1: one flat RCCL all-reduce), Adam over
@@ -244,8 +260,9 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
         dt = float(t.item())
     assert bool(torch.isfinite(loss))
     roofline = train_roofline(args, model_f, dev, n_rays) if rank == 0 else None
+    result = None
     if rank == 0:
-        print(json.dumps({
+        result = {
             "roofline": roofline,
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
@@ -255,10 +272,101 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist):
             "config": {"workload": f"configs[2]: {args.family}-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
                                    "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
                        "rays_per_step": n_rays * world, "parallelism": f"dp{world}",
-                       "mlp_precision": args.precision, "family": args.family}}), flush=True)
+                       "mlp_precision": args.precision, "family": args.family}}
+        if emit:
+            print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
-        dist.destroy_process_group()
+        if emit:
+            dist.destroy_process_group()
+    return result
+
+
+def bench_tiny(dev, steps=20):
+    """configs[0]: tiny_nerf 64x64 image, 32 samples (TN:111-159) -- the fused tiny kernels on the device.  Returns the result
+    and the inputs (weights, pose, focal) so that cpu_baseline_tiny can time the CPU oracle on the same image."""
+    import tiny_nerf as TN
+    torch.manual_seed(9458)                                             # TN:264
+    model = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
+    pose = frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    pose_d = pose.to(dev)
+
+    def once():
+        with torch.no_grad():
+            return TN.run_one_iter_of_tinynerf(64, 64, focal, pose_d, 2.0, 6.0, 32, None, TN.get_minibatches, 16384, model, 10)
+    for _ in range(3):
+        rgb = once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        rgb = once()
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / steps
+    assert rgb.shape == (64, 64, 3) and bool(torch.isfinite(rgb).all())
+    res = {"workload": "configs[0]: tiny_nerf 64x64 image, 32 samples per ray, VeryTinyNerfModel (63-128-128-4), forward",
+           "value": 4096 / (ms * 1e-3), "unit": "rays/s", "ms_per_image": ms, "images": steps,
+           "note": "host-launch bound on the device (ray bundle + two kernels per image of 4096 rays)"}
+    return res, ({k: v.detach().cpu() for k, v in model.state_dict().items()}, pose, focal)
+
+
+def cpu_baseline_tiny(params, pose, focal, reps=3):
+    """configs[0] on the host: the CPU oracle of tiny_nerf (TN:111-159) on the same weights / pose (the reference's own
+    CPU-runnable case)."""
+    from oracle import nerface_oracle as O
+    with torch.no_grad():
+        O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=torch.zeros(64, 64, 32))
+        cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
+    return {"value": 4096 / (cpu_ms * 1e-3), "unit": "rays/s", "ms_per_image": cpu_ms, "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} whole 64x64x32 images"}
+
+
+def pmc_traffic(precision, timeout=240):
+    """HBM bytes per fine-pass MLP launch, measured by THIS command: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
+    share a pass on gfx950, MI355X_MICROARCH.md) over tools/pmc_one_launch.py, which launches exactly the kernel the roofline
+    object times.  FETCH_SIZE / WRITE_SIZE are KiB; raw counters, no 2x correction (the dominant reads are 4-byte z loads,
+    not the 16 B/lane stream the guide's correction is calibrated on).  Returns (bytes or None, detail dict)."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, {"error": "rocprofv3 not found"}
+    kernel = "k_paper_mlp_fwd_bf16" if precision == "bf16x3" else "k_paper_mlp_fwd<"
+    got = {}
+    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            env = dict(os.environ, TMPDIR=tmp)
+            env.pop("RANK", None)
+            env.pop("WORLD_SIZE", None)
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "pmc_one_launch.py"), precision]
+            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+            dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode != 0 or not dbs:
+                return None, {"error": f"rocprofv3 pass {counter} failed (rc {r.returncode})", "tail": r.stdout.decode()[-400:]}
+            rows = sqlite3.connect(dbs[0]).execute(
+                "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+            hits = [(gx, v) for n, gx, v in rows if kernel in n]
+            big = max((gx for gx, _ in hits), default=None)               # the fine-pass launch is the kernel's largest grid
+            vals = [v for gx, v in hits if gx == big]
+            if not vals:
+                return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _ in rows})[:8]}
+            got[counter] = sum(vals) / len(vals) * 1024.0
+        return got["FETCH_SIZE"] + got["WRITE_SIZE"], {"fetch_bytes": got["FETCH_SIZE"], "write_bytes": got["WRITE_SIZE"],
+                                                       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) "
+                                                                 "run by bench.py on tools/pmc_one_launch.py in this run"}
+    except Exception as e:
+        return None, {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -267,15 +375,18 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="bf16x3",
-                    help="inference GEMM arithmetic: bf16x3 = split-bf16 (3 bf16 MFMAs per product, f32 accumulate; passes the "
-                         "1e-4 dB PSNR gate, tests/test_gpu_bf16.py); f32 = exact-f32 MFMA")
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip split_bf16 / train / tiny / PMC traffic)")
+    ap.add_argument("--precision", choices=["bf16x3", "f32"], default="f32",
+                    help="arithmetic of the HEADLINE: f32 (default) = exact-f32 MFMA, the reference's arithmetic; bf16x3 = split-bf16 "
+                         "(3 bf16 MFMAs per product, f32 accumulate; passes the 1e-4 dB PSNR gate).  The other one is reported "
+                         "beside it (`split_bf16` / `exact_f32`)")
     ap.add_argument("--chunksize", type=int, default=CHUNK, help="validation ray chunk (shipped configs: 65536)")
     ap.add_argument("--family", choices=["paper", "lcode"], default="paper",
                     help="train mode only: lcode = ConditionalBlendshapeLearnableCodeNeRFModel")
     ap.add_argument("--mode", choices=["eval", "train"], default="eval",
-                    help="eval (default) = BASELINE.json's metric; train = configs[2]/[4]: 2048 rays/iter, 64+64, fwd+bwd+Adam")
+                    help="eval (default) = BASELINE.json's metric; train = configs[2]/[4] as the headline: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=12288)
+    ap.add_argument("--train-steps", type=int, default=40, help="iterations of the `train` object of the eval line")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -326,53 +437,73 @@ def main():
                                              encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
                                              expressions=conds[i][0], background_prior=background, latent_code=conds[i][1])
 
-    for i in range(args.warmup):
-        out = step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.warmup, n_frames):
-        out = step(i)
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
+    def timed_frames():
+        """W warm-up frames, then exactly K frames between barrier + synchronize on both sides; max over ranks."""
+        for i in range(args.warmup):
+            out = step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(args.warmup, n_frames):
+            out = step(i)
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
+        return dt
 
+    dt = timed_frames()
     rays_total = world * args.steps * H * W
+    dtype_of = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 products, f32 accumulate)"}
     line = {
         "metric": "rays/sec at 512x512, 64 coarse + 128 fine samples", "value": rays_total / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32", "data": "synthetic",
+        "dtype": dtype_of[args.precision], "data": "synthetic",
         "config": {"workload": "configs[1]: paper-model eval forward, 512x512 frame, 64+128 samples, chunksize 65536, "
                                "perturb on, expression+latent conditioned, background prior; frames sharded over GPUs",
                    "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}",
                    "mlp_precision": args.precision},
     }
 
-    exact = None
-    if args.precision == "bf16x3":
-        # the same frames through the exact-f32 kernels (reported next to the headline, never as `value`)
-        nerf.set_mlp_precision("f32")
-        step(0)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(2):
-            step(i % n_frames)
-        torch.cuda.synchronize()
-        exact = (time.perf_counter() - t1) / 2
+    # ---- the same K frames (same warm-up, same bracketing) in the other arithmetic, beside the headline ------------------
+    other = "bf16x3" if args.precision == "f32" else "f32"
+    if not args.no_extras:
+        nerf.set_mlp_precision(other)
+        dt_o = timed_frames()
         nerf.set_mlp_precision(args.precision)
-    if exact is not None:
-        line["exact_f32"] = {"value": world * H * W / exact, "unit": "rays/s", "ms_per_step": 1e3 * exact,
-                             "note": "same workload on this rank with nerf.set_mlp_precision('f32') (exact-f32 MFMA kernels), 2 frames"}
+        line["split_bf16" if other == "bf16x3" else "exact_f32"] = {
+            "value": rays_total / dt_o, "unit": "rays/s", "ms_per_step": 1e3 * dt_o / max(args.steps, 1), "steps": args.steps,
+            "warmup": args.warmup, "dtype": dtype_of[other],
+            "note": f"same workload, frames and timing protocol with nerf.set_mlp_precision('{other}')"}
+
+    # ---- configs[2] (N>1: configs[4]): training iterations in both arithmetics --------------------------------------------
+    if not args.no_extras:
+        train = {}
+        keep_steps, keep_warm, keep_prec = args.steps, args.warmup, args.precision
+        for prec in ("f32", "bf16x3"):
+            args.steps, args.warmup, args.precision = args.train_steps, 5, prec
+            nerf.set_mlp_precision(prec)
+            mc_t, mf_t = synth_params(0, dev, "paper"), synth_params(1, dev, "paper")
+            r = bench_train(args, nerf, mc_t, mf_t, dev, rank, world, dist, emit=False)
+            if r is not None:
+                train[prec] = {"value": r["value"], "unit": r["unit"], "ms_per_iter": r["ms_per_step"], "iters": r["steps"],
+                               "warmup": r["warmup"], "roofline": r["roofline"]}
+        args.steps, args.warmup, args.precision = keep_steps, keep_warm, keep_prec
+        nerf.set_mlp_precision(args.precision)
+        if rank == 0:
+            train["workload"] = ("configs[2]: paper-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, noise 0.1, "
+                                 "latent table 1000x32, fwd + bwd + fused Adam" + ("" if world == 1 else
+                                 f"; configs[4]: data parallel over {world} GPUs, one frame per rank, flat gradient all-reduce (RCCL)"))
+            line["train"] = train
 
     if rank == 0:
         # ---- roofline of the dominant kernel: fused MLP forward, fine pass of one ray chunk ----------------
@@ -396,34 +527,40 @@ def main():
             return sum(ev[k].elapsed_time(ev[k + 1]) for k in range(n_launch)) / n_launch
 
         flops = float(CHUNK) * S * FLOP_PER_POINT
+        algo_bytes = CHUNK * S * (4 + 16) + 2 * CHUNK * 12 + 4 * ops.H.lib().nf_paper_packed_floats()   # z read + raw written, rays, weights once
         ms_f32 = timed(lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z))
         ms_b16 = timed(lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z))
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "mlp_fwd_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch_" + args.precision)
-            except Exception:
-                traffic = None
         f32_obj = {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2,false> (65536 rays x 192 samples per launch)",
                    "achieved": flops / (ms_f32 * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                    "frac": flops / (ms_f32 * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms_f32,
-                   "algorithmic_flops_per_launch": flops}
-        if args.precision == "bf16x3":
-            ach = flops / (ms_b16 * 1e-3) / 1e12
-            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms_b16 * 1e-3) / 1e12
-            line["roofline"] = {"bound": "mfma", "kernel": "k_paper_mlp_fwd_bf16 (65536 rays x 192 samples per launch)",
-                                "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
-                                "avg_launch_ms": ms_b16, "algorithmic_flops_per_launch": flops, "traffic": traffic,
-                                "executed_tflops": exe, "frac_executed": exe / PEAK_BF16_MFMA_TFLOPS,
-                                "note": "achieved counts ALGORITHMIC f32 FLOPs (1,100,032/point); each costs 3 bf16 MFMA FLOPs in the "
-                                        "split scheme, so frac cannot exceed 1/3; executed_* counts the issued MFMA FLOPs"}
-            line["roofline_exact_f32_kernel"] = f32_obj
-        else:
-            f32_obj["traffic"] = traffic
-            line["roofline"] = f32_obj
+                   "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes, "traffic": None}
+        ach = flops / (ms_b16 * 1e-3) / 1e12
+        exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms_b16 * 1e-3) / 1e12
+        b16_obj = {"bound": "mfma", "kernel": "k_paper_mlp_fwd_bf16 (65536 rays x 192 samples per launch)",
+                   "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
+                   "avg_launch_ms": ms_b16, "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes,
+                   "traffic": None, "executed_tflops": exe, "frac_executed": exe / PEAK_BF16_MFMA_TFLOPS,
+                   "note": "achieved counts ALGORITHMIC f32 FLOPs (1,100,032/point); each costs 3 bf16 MFMA FLOPs in the "
+                           "split scheme, so frac cannot exceed 1/3; executed_* counts the issued MFMA FLOPs"}
+        if world == 1 and not args.no_extras:
+            for prec, obj in (("f32", f32_obj), ("bf16x3", b16_obj)):
+                obj["traffic"], obj["traffic_detail"] = pmc_traffic(prec)
+        head_obj, other_obj = (f32_obj, b16_obj) if args.precision == "f32" else (b16_obj, f32_obj)
+        line["roofline"] = head_obj
+        key = "split_bf16" if other == "bf16x3" else "exact_f32"
+        line.setdefault(key, {})["roofline"] = other_obj
+        if world == 1 and not args.no_extras:
+            try:
+                line["tiny"], tiny_inputs = bench_tiny(dev)
+                if not args.no_cpu_baseline:
+                    line["tiny"]["cpu_baseline"] = cpu_baseline_tiny(*tiny_inputs)
+            except Exception as e:                                # an extra must never cost the headline
+                line["tiny"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
+            par = line["cpu_baseline"].get("parity_on_sample", {})
+            if isinstance(par, dict) and other in par and key in line:
+                line[key]["parity_on_sample"] = par[other]
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()

@@ -306,13 +306,21 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
 # --------------------------------------------------------------------------------------
 
 def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: float, n_coarse: int, n_fine: int,
-                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None, mlp=None):
+                t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None, mlp=None,
+                point_chunk: int = 65536):
     """Coarse pass -> hierarchical resample -> fine pass.  Returns the 7-tuple of T:162
     (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, weights_f[:, -1]).  Random tensors are injected
     (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates."""
     R = ro.shape[0]
     st = stages if stages is not None else {}
-    paper_mlp = mlp if mlp is not None else globals()["paper_mlp"]          # model family (default: the paper model)
+    mlp_fn = mlp if mlp is not None else globals()["paper_mlp"]             # model family (default: the paper model)
+
+    def paper_mlp(p, x, e, l):
+        # run_network feeds the model `chunksize` POINTS at a time (T:20-24, get_minibatches over the embedded points)
+        if x.shape[0] <= point_chunk:
+            return mlp_fn(p, x, e, l)
+        return torch.cat([mlp_fn(p, x[k:k + point_chunk], e, l) for k in range(0, x.shape[0], point_chunk)], dim=0)
+
     z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype, device=ro.device)
     raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far, rd_view), expr, latent).reshape(R, n_coarse, 4).clone()
     st["raw_c_mlp"] = raw.clone()

@@ -157,7 +157,8 @@ def test_product_has_no_cpu_path():
 
 def test_oracle_is_imported_only_by_the_checkers():
     """oracle/ is test infrastructure: nothing in the product package, the launchers or tools/ may import it; bench.py may only
-    inside its cpu_baseline leg (function cpu_baseline) and __graft_entry__ only as the smoke() / build() checker."""
+    inside its cpu_baseline legs (functions cpu_baseline, cpu_baseline_tiny) and __graft_entry__ only as the smoke() / build()
+    checker."""
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
     for base in ("4d-facial-avatars_amd", "tools"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
@@ -166,9 +167,12 @@ def test_oracle_is_imported_only_by_the_checkers():
                     src = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(src), os.path.join(dirpath, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
-    leg = bench[bench.index("def cpu_baseline("):]
-    leg = leg[:leg.index("\ndef ", 1)]
-    assert len(pat.findall(bench)) == len(pat.findall(leg)) > 0
+    n_legs = 0
+    for fn in ("def cpu_baseline(", "def cpu_baseline_tiny("):
+        leg = bench[bench.index(fn):]
+        leg = leg[:leg.index("\ndef ", 1)]
+        n_legs += len(pat.findall(leg))
+    assert len(pat.findall(bench)) == n_legs > 0
 
 
 def test_cfgnode_roundtrip():
