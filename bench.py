@@ -315,6 +315,7 @@ def cpu_baseline_tiny(params, pose, focal, reps=3):
     """configs[0] on the host: the CPU oracle of tiny_nerf (TN:111-159) on the same weights / pose (the reference's own
     CPU-runnable case)."""
     from oracle import nerface_oracle as O
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))                 # 131k points x 128 features: more threads only add overhead
     with torch.no_grad():
         O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10)
         t0 = time.perf_counter()

@@ -130,10 +130,10 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s, split):
             continue
         e = rel_l2(gh.cpu(), go)
         worst = max(worst, e)
-        assert e < (3e-4 if split else 1e-4), (k, e)      # split: forward activations AND the dX chain carry 2^-16 roundings
+        assert e < 1e-4, (k, e)      # SURVEY §8(d)(iii) gate in BOTH arithmetics (split-bf16 measured worst: 6e-5)
     e = rel_l2(g_lat.cpu(), lat.grad)
     print(f"mlp bwd ({n_rays}x{s}, split={split}): worst param rel L2 {worst:.2e}, latent {e:.2e}")
-    assert e < (3e-4 if split else 1e-4)
+    assert e < 1e-4
     if split:     # the split-bf16 dW GEMMs against the exact-f32 ones on the SAME saved activations and dZ
         grads_x, g_lat_x = ops.paper_mlp_bwd(m, pk, cond, z.to(gpu), d_raw.to(gpu), saved, split=True, exact_dw=True)
         for (k, _), gs, gx in zip(m.named_parameters(), grads, grads_x):
@@ -174,13 +174,13 @@ def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
             # pre-activation rounds across zero -- each flip moves a gradient tensor by O(1/sqrt(#points)) -- and the fine
             # pass inherits the resampled-depth sensitivity (test_gpu_e2e.TOL).  The 1e-4 gate on the backward arithmetic
             # itself is enforced mask-consistently in test_paper_mlp_bwd / test_volume_render_bwd above.
-            assert e < 3e-3, (tag, k, e)
+            assert e < 1.5e-3, (tag, k, e)                  # measured worst 6.2e-4 (one flipped ReLU unit of 24 rays x 128 points)
             want = float(gold[f"norm:{tag}.{k}"])
-            assert abs(float(v.grad.double().norm()) - want) <= 2e-3 * want + 1e-9, (tag, k)
+            assert abs(float(v.grad.double().norm()) - want) <= 1e-3 * want + 1e-9, (tag, k)
     e_lat = rel_l2(latent.grad.cpu(), lat.grad)
     e_ref = rel_l2(latent.grad.cpu(), torch.from_numpy(gold["latent"]))
     print(f"train step: worst param rel L2 {worst:.2e}; latent vs oracle(fp64) {e_lat:.2e}, vs reference autograd {e_ref:.2e}")
-    assert e_lat < 2e-3 and e_ref < 2e-3
+    assert e_lat < 1e-4 and e_ref < 1e-4                     # measured 7.6e-6 / 7.1e-6
 
 
 def test_adam_step_moves_live_parameters(hip_lib, gpu):

@@ -13,12 +13,13 @@ from tests import util as U
 pytestmark = pytest.mark.gpu
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
 NAMES7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
-# Absolute tolerances per output.  Coarse outputs see only fp32 accumulation-order noise.  Fine outputs
-# additionally see the resampled depths: a 1-ulp difference in a z_sample (different but equally valid cumsum
-# association in the CDF) is amplified by the synthetic x1000 density head (d sigma / d z ~ 1e5), which is why the
-# fine pass is ALSO checked stage-wise on the oracle's own depths (test_fine_pass_on_oracle_depths, tight) and
-# end-to-end through the 1e-4 dB PSNR gate below.
-TOL = dict(rgb_c=3e-6, rgb_f=5e-4, acc_c=1e-5, acc_f=1e-5, w_last=5e-4, disp_c=1e-5, disp_f=2e-3)
+# Absolute tolerances per output, "hard" family (x1000 density head).  Coarse outputs see only fp32 accumulation-order noise.
+# Fine outputs additionally see the resampled depths: the CDF table itself is reproduced bit for bit on identical weights
+# (test_sample_pdf_bit_exact), but the coarse WEIGHTS carry fp32 accumulation noise (~1e-7), which moves a z_sample by an ulp
+# or two, and the synthetic x1000 head (d sigma / d z ~ 1e5) amplifies that: measured worst rgb_f 1.3e-4, w_last 3.5e-4.
+# The fine pass is ALSO checked stage-wise on the oracle's own depths (test_fine_pass_on_oracle_depths, tight), on the "soft"
+# family with SURVEY §8(d)'s own gates, and on the whole frame against an fp64 evaluation through the 1e-4 dB PSNR gate.
+TOL = dict(rgb_c=3e-6, rgb_f=3e-4, acc_c=1e-5, acc_f=1e-5, w_last=5e-4, disp_c=1e-5, disp_f=5e-5)
 # "soft" family (SURVEY §8(d)'s density head, fc_alpha x40 / bias 0.5): the survey's own per-stage gates -- rgb 2e-5,
 # weights 1e-5, z_samples 1e-5 (disparities are ~2..5: 2e-5 absolute is 1e-5 relative)
 TOL_SOFT = dict(rgb_c=3e-6, rgb_f=2e-5, acc_c=1e-5, acc_f=1e-5, w_last=1e-5, disp_c=2e-5, disp_f=2e-5)
