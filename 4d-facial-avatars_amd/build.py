@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libnerface_hip.so")
-SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_mlp_bf16.hip", "nf_mlp_bf16_train.hip", "nf_mlp_bf16_bwd.hip", "nf_mlp_bf16_dw.hip", "nf_tiny.hip", "nf_mlp_lcode.hip", "nf_mlp_lcode_bwd.hip", "nf_mlp_lcode_bf16.hip", "nf_mlp_lcode_bf16_train.hip", "nf_mlp_lcode_bf16_bwd.hip", "nf_pipeline.hip", "nf_mlp_encoded.hip"]
+SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_mlp_bf16.hip", "nf_mlp_f16.hip", "nf_mlp_bf16_train.hip", "nf_mlp_bf16_bwd.hip", "nf_mlp_bf16_dw.hip", "nf_tiny.hip", "nf_mlp_lcode.hip", "nf_mlp_lcode_bwd.hip", "nf_mlp_lcode_bf16.hip", "nf_mlp_lcode_bf16_train.hip", "nf_mlp_lcode_bf16_bwd.hip", "nf_pipeline.hip", "nf_mlp_encoded.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 
@@ -46,11 +46,23 @@ def _includes(src: str, seen=None) -> set:
     return seen
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not _stale():
+def build_variant(suffix: str, extra_flags, verbose: bool = True) -> str:
+    """Experiment builds: lib/libnerface_hip_<suffix>.so compiled with extra -D switches (own object directory).  Selected at
+    run time with NERFACE_HIP_LIB=<path>; never loaded by default.  Used for same-session A/B kernel timings (profiles/)."""
+    global OUT
+    keep = OUT
+    OUT = os.path.join(OUT_DIR, f"libnerface_hip_{suffix}.so")
+    try:
+        return build(force=False, verbose=verbose, _extra=list(extra_flags), _obj=f"obj_{suffix}", _always=True)
+    finally:
+        OUT = keep
+
+
+def build(force: bool = False, verbose: bool = True, _extra=(), _obj="obj", _always=False) -> str:
+    if not force and not _always and not _stale():
         return OUT
     os.makedirs(OUT_DIR, exist_ok=True)
-    obj_dir = os.path.join(OUT_DIR, "obj")                      # object cache (git-ignored): incremental rebuilds
+    obj_dir = os.path.join(OUT_DIR, _obj)                       # object cache (git-ignored): incremental rebuilds
     os.makedirs(obj_dir, exist_ok=True)
     objs = []
     cc = _hipcc()
@@ -64,7 +76,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         newest = max(os.path.getmtime(d) for d in _includes(src) | {os.path.abspath(__file__)})
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             continue
-        procs.append((s, subprocess.Popen([cc, *FLAGS, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        procs.append((s, subprocess.Popen([cc, *FLAGS, *_extra, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         try:
             out, _ = p.communicate(timeout=900)
@@ -85,4 +97,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
 
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python build.py --variant NAME -DFOO=1 ...
+        print(build_variant(sys.argv[2], sys.argv[3:]))
+    else:
+        build(force="--force" in sys.argv)

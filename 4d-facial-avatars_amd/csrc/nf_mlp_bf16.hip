@@ -66,6 +66,8 @@ static void nf_build_table_bf16(std::vector<uint32_t>& t) {
     }
 }
 
+void nf_build_table_bf16_shared(std::vector<uint32_t>& t) { nf_build_table_bf16(t); }      // also the split-fp16 stream's table
+
 static NfPackTable g_paper_table_b;
 
 extern "C" size_t nf_paper_packed_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }

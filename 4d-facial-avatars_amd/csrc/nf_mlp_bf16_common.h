@@ -3,7 +3,21 @@
 #include "nf_common.h"
 #include "nf_mlp_layout.h"
 
+// Element type of the split operands.  NFB_F16 = 0: bf16 pairs (x = hi + lo keeps 16 significand bits, f32's exponent range);
+// NFB_F16 = 1: fp16 pairs (22 significand bits -- fp32-class accuracy at the same three MFMAs per product; the narrow fp16
+// exponent range is handled by a per-layer power-of-two weight scale chosen at pack time, see nf_mlp_f16.hip).
+#ifndef NFB_F16
+#define NFB_F16 0
+#endif
+#if NFB_F16
+typedef _Float16 nfb_elt;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));      // (the name is historical: 8 split-operand elements of type nfb_elt)
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 nfb_elt;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

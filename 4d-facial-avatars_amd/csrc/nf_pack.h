@@ -93,3 +93,78 @@ static inline int nf_pack_split_bf16(NfPackTable& cache, Build build, const floa
                        n_entries);
     NF_RETURN_LAUNCH();
 }
+
+// ---- fp16 split streams (nf_mlp_f16.hip): x = hi + lo in fp16 keeps 22 significand bits, but fp16's exponent range is
+// narrow, so every layer's weights are multiplied by a power of two 2^e chosen from the layer's largest |w| such that the
+// scaled maximum lies in [2^13, 2^14): the `lo` parts (<= 2^-11 of the value) then stay normal fp16 numbers for every
+// weight down to 2^-17 of the layer's largest.  Tail of the stream buffer (NF_F16_TAIL_BYTES behind the blocks):
+// [NL] bias scales s_W * act_scale | [NL] inverse weight scales 1 / s_W | [NL] scratch (|w| maxima as uint bits) | ... |
+// dword NF_F16_FLAG_WORD: range-guard flag set by the forward kernel.
+#define NF_F16_TAIL_BYTES 256
+#define NF_F16_FLAG_WORD 48                  // dword index in the tail: sticky "non-finite output" flag of the forward kernel
+template <int NL> struct NfLayerPairs { int off[NL + 1]; };
+
+template <int N, int TAG, int NL>
+__global__ void __launch_bounds__(256) k_stream_absmax(NfPackPtrs<N> ptrs, const uint32_t* __restrict__ table, int n_entries,
+                                                       NfLayerPairs<NL> lp, unsigned* __restrict__ amax_bits) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+        const uint32_t code = table[e], id = code >> 24;
+        if (id == 0xFFu) continue;
+        const float w = fabsf(ptrs.p[id][code & 0xFFFFFFu]);
+        const int pair = e >> 9;
+        int l = 0;
+        while (l + 1 < NL && pair >= lp.off[l + 1]) ++l;
+        if (w > 0.0f && w < INFINITY) atomicMax(amax_bits + l, __float_as_uint(w));
+    }
+}
+
+__device__ __forceinline__ float nf_f16_layer_scale(unsigned amax_bits) {
+    const float amax = __uint_as_float(amax_bits);
+    if (!(amax > 0.0f)) return 1.0f;
+    int k;
+    (void)frexpf(amax, &k);                         // amax = m 2^k, m in [0.5, 1)
+    int e = 14 - k;
+    e = e < -24 ? -24 : (e > 40 ? 40 : e);
+    return ldexpf(1.0f, e);
+}
+
+template <int N, int TAG, int NL>
+__global__ void __launch_bounds__(256) k_pack_split_f16(NfPackPtrs<N> ptrs, const uint32_t* __restrict__ table, _Float16* __restrict__ stream,
+                                                        int n_entries, NfLayerPairs<NL> lp, float* __restrict__ tail, float act_scale) {
+    const unsigned* amax_bits = reinterpret_cast<const unsigned*>(tail + 2 * NL);
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n_entries; e += gridDim.x * blockDim.x) {
+        const uint32_t code = table[e], id = code >> 24;
+        const int pair = e >> 9, within = e & 511;
+        int l = 0;
+        while (l + 1 < NL && pair >= lp.off[l + 1]) ++l;
+        const float sc = nf_f16_layer_scale(amax_bits[l]);
+        const float w = id == 0xFFu ? 0.0f : ptrs.p[id][code & 0xFFFFFFu] * sc;
+        const _Float16 hi = (_Float16)w;
+        const _Float16 lo = (_Float16)(w - (float)hi);
+        stream[(size_t)(2 * pair) * 512 + within] = hi;
+        stream[(size_t)(2 * pair + 1) * 512 + within] = lo;
+        if (e < NL) {
+            const float s = nf_f16_layer_scale(amax_bits[e]);
+            tail[e] = s * act_scale;
+            tail[NL + e] = 1.0f / s;
+        }
+    }
+}
+
+template <int N, int TAG, int NL, class Build>
+static inline int nf_pack_split_f16(NfPackTable& cache, Build build, const float* const* params, void* stream_out, int n_entries,
+                                    const NfLayerPairs<NL>& lp, float act_scale, nf_stream_t stream) {
+    NfPackPtrs<N> ptrs;
+    if (!stream_out || nf_pack_ptrs<N>(params, ptrs)) return NF_EINVAL;
+    uint32_t* table = nullptr;
+    const int rc = cache.get(build, &table);
+    if (rc) return rc;
+    float* tail = reinterpret_cast<float*>(reinterpret_cast<char*>(stream_out) + (size_t)n_entries * 4);   // 2 blocks x 2 bytes per entry
+    hipError_t e = hipMemsetAsync(tail, 0, NF_F16_TAIL_BYTES, nf_s(stream));
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((k_stream_absmax<N, TAG, NL>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, n_entries, lp,
+                       reinterpret_cast<unsigned*>(tail + 2 * NL));
+    hipLaunchKernelGGL((k_pack_split_f16<N, TAG, NL>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table,
+                       reinterpret_cast<_Float16*>(stream_out), n_entries, lp, tail, act_scale);
+    NF_RETURN_LAUNCH();
+}

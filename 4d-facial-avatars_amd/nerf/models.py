@@ -80,6 +80,8 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
             return raw, (packed, cond, saved, pb is not None)
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
+        if ops.get_mlp_precision() == "f16x3":
+            return ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z, rd_view), None
         return ops.paper_mlp_fwd(packed, cond, ro, rd, z, rd_view), None
 
     def hip_backward(self, state, z, d_raw):

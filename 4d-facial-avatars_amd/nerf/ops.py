@@ -27,7 +27,9 @@ PAPER_KEYS = (
 # "bf16x3" = split-bf16, three bf16 MFMAs per product with f32 accumulation (~2^-16 relative per product, 3x faster).
 # The switch applies to inference AND to a training step: under "bf16x3" the training forward, the dX chain and the
 # weight-gradient GEMMs all run on the split-bf16 kernels (paper_mlp_bwd(..., exact_dw=True) keeps the dW GEMMs exact).
-_VALID_PRECISIONS = ("f32", "bf16x3")
+# "f16x3" = split-fp16: the same three-MFMA scheme on fp16 pairs (22 operand bits, per-layer power-of-two weight scales):
+# fp32-class accuracy at the bf16x3 speed, inference only (a training step under "f16x3" runs the exact-f32 kernels).
+_VALID_PRECISIONS = ("f32", "bf16x3", "f16x3")
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
 
 
@@ -131,12 +133,35 @@ class PaperWeights:
         self._versions_b = None
         self.packed_bt = None           # transposed (hi, lo) bf16 stream for the split-bf16 backward chain
         self._versions_bt = None
+        self.packed_h = None            # (hi, lo) fp16 stream + per-layer scales for the split-fp16 forward
+        self._versions_h = None
 
     def invalidate(self) -> None:
         """Drop every cached image.  The caches follow in-place updates through the parameters' version counters
         (optimizer.step(), load_state_dict(), copy_ under no_grad); writes that bypass the counter -- through `p.data`, or by
         a collective -- are NOT seen: call this (or model.hip_weights().invalidate()) after such a write."""
-        self._versions = self._versions_t = self._versions_b = self._versions_bt = None
+        self._versions = self._versions_t = self._versions_b = self._versions_bt = self._versions_h = None
+
+    def get_f16(self) -> torch.Tensor:
+        sig = self._signature()
+        if self.packed_h is None or sig != self._versions_h:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed_h is None or self.packed_h.device != dev:
+                self.packed_h = torch.empty(lib.nf_paper_packed_f16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack_f16(arr, H.ptr(self.packed_h), H.stream_ptr(dev)), "nf_paper_pack_f16")
+            self._versions_h = sig
+        return self.packed_h
+
+    def f16_range_flag(self) -> Optional[torch.Tensor]:
+        """0-d int32 device tensor: non-zero once the split-fp16 forward produced a non-finite output with the current stream
+        (an activation left fp16's range).  None if the split-fp16 stream was never built."""
+        if self.packed_h is None:
+            return None
+        off = H.lib().nf_paper_f16_flag_offset()
+        return self.packed_h[off:off + 4].view(torch.int32)[0]
 
     def get_t(self) -> torch.Tensor:
         """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
@@ -227,6 +252,27 @@ def paper_mlp_fwd_bf16(packed_b, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
         H.check(H.lib().nf_paper_mlp_fwd_bf16(H.ptr(packed_b), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
                                               n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd_bf16")
     return raw
+
+
+def paper_mlp_fwd_f16(packed_h, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
+    """Split-fp16 (3 x fp16 MFMA on scaled weights, f32 accumulate) forward; fp32-class accuracy (see csrc/nf_mlp_f16.hip)."""
+    dev = H.require_device(cond, ro, rd, z, rd_view)
+    n_rays, n_samples = z.shape
+    raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_paper_mlp_fwd_f16(H.ptr(packed_h), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                             n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd_f16")
+    return raw
+
+
+def check_f16_range(*models) -> None:
+    """Raise if the split-fp16 kernels of any of `models` flagged a non-finite output since their weights were last packed
+    (one 4-byte read-back per model; called once per rendered frame, never inside a ray chunk)."""
+    flags = [m.hip_weights().f16_range_flag() for m in models if m is not None and hasattr(m, "hip_weights")]
+    flags = [f for f in flags if f is not None]
+    if flags and int(torch.stack(flags).sum().item()) != 0:
+        raise RuntimeError('nerf.set_mlp_precision("f16x3"): an activation left the fp16 range (|x| >= 4094) and the outputs are not '
+                           'finite -- render this model with "f32" or "bf16x3"')
 
 
 def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):

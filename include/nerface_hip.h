@@ -85,6 +85,19 @@ int nf_paper_pack_bf16(const float* const* params, void* packed_bf16, nf_stream_
 int nf_paper_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
                           const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                           nf_stream_t stream);
+
+/* ---- K4, split-fp16 variant ("f16x3", csrc/nf_mlp_f16.hip): same contract as nf_paper_mlp_fwd, every product evaluated as
+ * three fp16 MFMAs with f32 accumulation on a per-layer power-of-two-scaled weight stream: fp32-CLASS accuracy (22 operand
+ * significand bits; measured error against fp64 within ~2x of the exact-f32 kernel) at the split-bf16 kernel's speed.
+ * `packed_f16` = nf_paper_packed_f16_bytes() bytes from nf_paper_pack_f16 (stream blocks + per-layer scales).
+ * Valid while |activations| < 4094 (fp16 range / 2^4); replaces M:236-261 like nf_paper_mlp_fwd.
+ * Range guard: if an activation leaves fp16's range the point's outputs are non-finite and the kernel sets a sticky 32-bit
+ * flag at byte nf_paper_f16_flag_offset() of `packed_f16` (cleared by nf_paper_pack_f16); callers poll it per frame.      */
+size_t nf_paper_f16_flag_offset(void);
+size_t nf_paper_packed_f16_bytes(void);
+int nf_paper_pack_f16(const float* const* params, void* stream_out, nf_stream_t stream);
+int nf_paper_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                         const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
 /* training forward on the split-bf16 kernel: also fills `saved` (f32, same layout as nf_paper_mlp_fwd_train); the
  * backward (nf_paper_mlp_bwd) stays on the exact-f32 kernels.                                                */
 int nf_paper_mlp_fwd_train_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
