@@ -81,6 +81,14 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
         if ops.get_mlp_precision() == "f16x3":
+            key = (hw._signature(), expr.data_ptr(), latent.data_ptr(), expr._version, latent._version)
+            if getattr(self, "_f16_probe_key", None) != key:      # once per (weights, conditioning): i.e. once per frame and model
+                amax = ops.f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far)
+                if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
+                    raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g} on a '
+                                       f'sample of this frame, within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit '
+                                       f'({ops.F16_ACT_LIMIT:g}) -- render this model with "f32" or "bf16x3"')
+                self._f16_probe_key = key
             return ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z, rd_view), None
         return ops.paper_mlp_fwd(packed, cond, ro, rd, z, rd_view), None
 

@@ -265,13 +265,35 @@ def paper_mlp_fwd_f16(packed_h, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
     return raw
 
 
+F16_ACT_LIMIT = 65504.0 / 16.0          # largest |activation| the split-fp16 kernel represents (fp16 max / its 2^4 pre-scale)
+F16_PREFLIGHT_MARGIN = 4.0               # the probe refuses a model whose sampled activations come within 4x of that limit
+
+
+def f16_preflight(model, ro, rd, z, rd_view, expr, latent, near, far, max_rays: int = 256, max_samples: int = 8) -> float:
+    """Range probe for the split-fp16 kernel: evaluate the EXACT-f32 training forward (which writes every layer's activations)
+    on a strided sample of the chunk's points and return the largest hidden |activation|.  ~2k points: microseconds of GPU
+    time and one host read-back; called once per frame and model by run_one_iter_of_nerf under "f16x3"."""
+    n_rays, n_s = z.shape
+    rs = max(1, n_rays // max_rays)
+    ss = max(1, n_s // max_samples)
+    ro_s, rd_s = ro[::rs].contiguous(), rd[::rs].contiguous()
+    z_s = z[::rs, ::ss].contiguous()
+    rv_s = None if rd_view is None else rd_view[::rs].contiguous()
+    hw = model.hip_weights()
+    packed = hw.get()
+    cond = paper_condition(packed, expr, latent, near, far)
+    _, (saved,) = paper_mlp_fwd_train(packed, cond, ro_s, rd_s, z_s, rv_s)
+    n = z_s.numel()
+    return float(saved[64 * n:2240 * n].abs().max().item())          # sections S_H0 .. S_D2 (csrc/nf_mlp_layout.h): every hidden layer output
+
+
 def check_f16_range(*models) -> None:
     """Raise if the split-fp16 kernels of any of `models` flagged a non-finite output since their weights were last packed
     (one 4-byte read-back per model; called once per rendered frame, never inside a ray chunk)."""
     flags = [m.hip_weights().f16_range_flag() for m in models if m is not None and hasattr(m, "hip_weights")]
     flags = [f for f in flags if f is not None]
     if flags and int(torch.stack(flags).sum().item()) != 0:
-        raise RuntimeError('nerf.set_mlp_precision("f16x3"): an activation left the fp16 range (|x| >= 4094) and the outputs are not '
+        raise RuntimeError('nerf.set_mlp_precision("f16x3"): an activation left the fp16 range (|x| >= 4094) and a density output is not '
                            'finite -- render this model with "f32" or "bf16x3"')
 
 

@@ -77,8 +77,9 @@ def test_f16x3_weight_scales_follow_the_layers(hip_lib, gpu):
 
 
 def test_f16x3_range_guard_fails_loudly(hip_lib, gpu):
-    """Activations beyond fp16's range (here: a hidden layer scaled by 2^14) make the outputs non-finite; the kernel flags it and
-    run_one_iter_of_nerf raises instead of returning a corrupted frame.  Repacking (a parameter update) clears the flag."""
+    """Activations beyond fp16's range (here: a hidden layer scaled by 2^14): the pre-flight probe (exact-f32 forward on a sample
+    of the frame's points, 4x margin) makes run_one_iter_of_nerf raise instead of returning a corrupted frame; the kernel itself
+    saturates instead of producing NaN, and flags a non-finite density (an unsaturated fc_feat overflow)."""
     import nerf
     c = C.build_case("eval_det_64_128")
     c["p_coarse"] = dict(c["p_coarse"])
@@ -86,6 +87,21 @@ def test_f16x3_range_guard_fails_loudly(hip_lib, gpu):
     nerf.set_mlp_precision("f16x3")
     with pytest.raises(RuntimeError, match="fp16 range"):
         U.run_product(nerf, c, gpu)
+    # the kernel alone (no probe): finite colours thanks to the saturating ReLU -- wrong, but not NaN-poisoned
+    from nerf import ops
+    m = U.make_model(nerf, c["p_coarse"], gpu)
+    cond = ops.paper_condition(m.hip_weights().get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    z = torch.linspace(0.2, 0.8, 64).expand(c["n_rays"], 64).contiguous().to(gpu)
+    raw = ops.paper_mlp_fwd_f16(m.hip_weights().get_f16(), cond, c["ro"].to(gpu), c["rd"].to(gpu), z)
+    assert bool(torch.isfinite(raw[..., :3]).all())
+    # fc_feat has no ReLU: blowing IT up reaches sigma as inf / NaN and sets the kernel's sticky flag
+    p2 = dict(C.build_case("eval_det_64_128")["p_coarse"])
+    p2["fc_feat.weight"] = p2["fc_feat.weight"] * 2.0 ** 16
+    m2 = U.make_model(nerf, p2, gpu)
+    cond2 = ops.paper_condition(m2.hip_weights().get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    ops.paper_mlp_fwd_f16(m2.hip_weights().get_f16(), cond2, c["ro"].to(gpu), c["rd"].to(gpu), z)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        ops.check_f16_range(m2)
     nerf.set_mlp_precision("f32")
     out, *_ = U.run_product(nerf, c, gpu)                        # the exact-f32 kernels render the same model
     assert bool(torch.isfinite(out[0]).all())

@@ -3,6 +3,9 @@
 //   MODE 1: 8 waves x 16 points, v_mfma_f32_16x16x32_bf16, 16 output tiles of 16 (two waves per SIMD)
 // Per stage (32 K values x 256 outputs x (hi, lo) = 32 KiB of weights): LDS-DMA into a 4-deep ring, every wave reads the
 // whole stage from LDS and issues 3 MFMAs per (tile, k-step); one barrier per stage.  Prints achieved bf16 TFLOP/s.
+// STORES = 1 models the TRAINING kernels: after every 8 stages (one 256-wide layer) each wave writes its f32 accumulator
+// tiles to global memory with 16-byte stores (1 KiB per wave instruction): 32 store instructions per layer for a 32-point
+// wave, 16 for a 16-point wave -- the question being whether a second wave per SIMD hides the store-issue stalls.
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -14,8 +17,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE>
-__global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __restrict__ w, int n_stages, float* __restrict__ out) {
+template <int MODE, int STORES>
+__global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __restrict__ w, int n_stages, float* __restrict__ out,
+                                                              float* __restrict__ sink) {
     constexpr int NW = MODE ? 8 : 4;
     constexpr int PIECES = 32 / NW;                 // 1-KiB DMA pieces per wave and stage
     __shared__ __attribute__((aligned(16))) char lds[NBUF * STAGE_BYTES];
@@ -58,6 +62,22 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
                     for (int t = 0; t < 8; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k == 0 ? al[t] : ah[t], k == 1 ? bl[u] : bh[u], acc[t], 0, 0, 0);
             }
+            if (STORES && (st & 7) == 7) {                     // a layer ends: 8 tiles x 4 stores of 16 B per lane
+                // STORES 1: row-major [point][256 features] (a wave instruction touches 64 lines, 16 B each);
+                // STORES 2: wave-linear blocks (a wave instruction writes 1 KiB contiguous = 8 full lines)
+                // STORES 3: row-major again, but a wave instruction covers 8 points x one full 128-byte line each (lane = point%8 x 16-byte
+                //           chunk; the address pattern a store through an LDS transpose would have -- data content is irrelevant here)
+                float* dst = STORES == 1 ? sink + ((size_t)(blockIdx.x * 4 + wave) * 32 + (lane & 31)) * 256 + 4 * (lane >> 5)
+                           : STORES == 2 ? sink + (size_t)(blockIdx.x * 4 + wave) * 32 * 256 + 4 * lane
+                                         : sink + ((size_t)(blockIdx.x * 4 + wave) * 32 + (lane >> 3)) * 256 + 4 * (lane & 7);
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        *reinterpret_cast<f32x4*>(dst + (STORES == 1 ? 32 * t + 8 * q : STORES == 2 ? 256 * (4 * t + q) : 32 * t + 8 * 256 * q)) =
+                            (f32x4){acc[t][4 * q], acc[t][4 * q + 1], acc[t][4 * q + 2], acc[t][4 * q + 3]};
+                wait_vm<2 * PIECES + 32>();
+            } else
             wait_vm<2 * PIECES>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -89,6 +109,12 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
                     for (int t = 0; t < 8; ++t)
                         acc[q * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k == 0 ? al[t] : ah[t], k == 1 ? bl[0] : bh[0], acc[q * 8 + t], 0, 0, 0);
             }
+            if (STORES && (st & 7) == 7) {                     // a layer ends: 16 tiles x 1 store of 16 B per lane
+                float* dst = sink + ((size_t)(blockIdx.x * 8 + wave) * 16 + (lane & 15)) * 256 + 4 * (lane >> 4);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(dst + 16 * t) = acc[t];
+                wait_vm<2 * PIECES + 16>();
+            } else
             wait_vm<2 * PIECES>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
@@ -105,17 +131,23 @@ int main(int argc, char** argv) {
     char* w; float* out;
     hipMalloc(&w, 64 * STAGE_BYTES + 65536); hipMemset(w, 0, 64 * STAGE_BYTES + 65536);
     hipMalloc(&out, grid * 512 * sizeof(float));
+    float* sink; hipMalloc(&sink, (size_t)grid * 128 * 256 * sizeof(float));       // one 128-point x 256-feature tile per workgroup
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode) {
+    for (int stores = 0; stores < 4; ++stores)
+    for (int mode = 0; mode < (stores >= 2 ? 1 : 2); ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
-            if (mode == 0) hipLaunchKernelGGL(k_ring<0>, dim3(grid), dim3(256), 0, 0, w, n_stages, out);
-            else hipLaunchKernelGGL(k_ring<1>, dim3(grid), dim3(512), 0, 0, w, n_stages, out);
+            if (mode == 0 && !stores) hipLaunchKernelGGL((k_ring<0, 0>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
+            else if (mode == 0 && stores == 1) hipLaunchKernelGGL((k_ring<0, 1>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
+            else if (mode == 0 && stores == 2) hipLaunchKernelGGL((k_ring<0, 2>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
+            else if (mode == 0) hipLaunchKernelGGL((k_ring<0, 3>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
+            else if (!stores) hipLaunchKernelGGL((k_ring<1, 0>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
+            else hipLaunchKernelGGL((k_ring<1, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             // per stage and workgroup: 128 points x 256 outputs x 32 K x 2 flop x 3 products
             const double flop = (double)grid * n_stages * 128.0 * 256 * 32 * 2 * 3;
-            printf("mode %d rep %d: %.3f ms  %.1f TFLOP/s issued bf16 (%.2f of 2500)  err=%d\n", mode, rep, ms, flop / ms / 1e9, flop / ms / 1e9 / 2500, (int)hipGetLastError());
+            printf("stores %d mode %d rep %d: %.3f ms  %.1f TFLOP/s issued bf16 (%.2f of 2500)  err=%d\n", stores, mode, rep, ms, flop / ms / 1e9, flop / ms / 1e9 / 2500, (int)hipGetLastError());
         }
     }
     return 0;
