@@ -139,3 +139,31 @@ __device__ __forceinline__ void nf_encode_point(float px, float py, float pz, in
     }
 }
 
+// ---- backward-chain helpers (nf_mlp_bwd.hip, nf_mlp_lcode_bwd.hip, nf_tiny_bwd.hip) --------------------------------
+template <int NT, int NO>
+__device__ __forceinline__ void nf_zero_acc(f32x4 (&acc)[NT][16]) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t][no] = (f32x4){0.f, 0.f, 0.f, 0.f};
+}
+
+// acc *= [X > 0] with X read from the saved activations ([n_points][width] row-major)
+template <int NT, int NO>
+__device__ __forceinline__ void nf_mask_by_saved(f32x4 (&acc)[NT][16], const float* __restrict__ sec, int width, int64_t p0,
+                                                 int64_t n_points, int lane) {
+    const int g = lane >> 4, c = lane & 15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            const f32x4 x = *reinterpret_cast<const f32x4*>(sec + p * width + 16 * no + 4 * g);
+            f32x4 v = acc[t][no];
+            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
+            acc[t][no] = v;
+        }
+    }
+}
+

@@ -98,7 +98,8 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
     cx.lds = lds;
     cx.gsrc = wstream + cx.lane * 16;
     const int h = cx.lane >> 5, c = cx.lane & 31;
-    const int64_t p_raw = ((int64_t)blockIdx.x * 4 + cx.wave) * 32 + c;
+    const int64_t p_tile = ((int64_t)blockIdx.x * 4 + cx.wave) * 32;                 // first point of this wave's tile
+    const int64_t p_raw = p_tile + c;
     const int64_t p = p_raw < n_points ? p_raw : n_points - 1;
     const bool live = p_raw < n_points;
     const int64_t n = n_points;
@@ -135,7 +136,7 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
 #define NFB_LC_BWD_FINISH(NO_, MASK_, ZSEC_)                                                             \
     do {                                                                                                 \
         if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                 \
-        if (live) nfb_save_tiles<NO_>(acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p, h);                 \
+        nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
         nfb_to_operands<NO_, false>(acc, bh, bl, 0);                                                     \
     } while (0)
     // mask indices: layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
@@ -162,7 +163,7 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
     NFB_LC_BWD_FINISH(8, 0, Z_X0);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(5, acc, bh, bl);                                         // layer1 has no activation: dZ = d(out)
-    if (live) nfb_save_tiles<8>(acc, dz + (int64_t)Z_L1 * n, 256, p, h);
+    nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L1 * n, 256, p_tile, n);
 #undef NFB_LC_BWD_FINISH
 }
 

@@ -157,7 +157,7 @@ template <int NCH>
 __global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restrict__ raw, const float* __restrict__ z,
                                                            const float* __restrict__ rd, const float* __restrict__ noise,
                                                            const float* __restrict__ bg, const float* __restrict__ d_rgb,
-                                                           int64_t n_rays, int S, int white_bg, float* __restrict__ d_raw) {
+                                                           int64_t n_rays, int S, int white_bg, float* __restrict__ d_raw, int mode) {
     const int lane = nf_lane();
     const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + (threadIdx.x >> 6);
     if (ray >= n_rays) return;
@@ -165,7 +165,7 @@ __global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restri
     const float* z_row = z + ray * S;
     const float* noise_row = noise ? noise + ray * S : nullptr;
     const float* bg_ray = bg ? bg + ray * 3 : nullptr;
-    const float norm = nf_rd_norm(rd + ray * 3);
+    const float norm = (mode & 1) ? nf_rd_norm(rd + ray * 3) : 1.0f;
     const float g0 = d_rgb[ray * 3 + 0], g1 = d_rgb[ray * 3 + 1], g2 = d_rgb[ray * 3 + 2];
     const float gw_white = white_bg ? -(g0 + g1 + g2) : 0.0f;
 
@@ -178,7 +178,7 @@ __global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restri
         const bool on = s < S;
         alpha[k] = 0.f; dist[k] = 0.f; pre[k] = 0.f; c[k][0] = c[k][1] = c[k][2] = 0.f; isbg[k] = false;
         if (on) {
-            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S);
+            const NfSample q = nf_load_sample(raw_row, z_row, noise_row, bg_ray, norm, s, S, mode);
             alpha[k] = q.alpha; dist[k] = q.dist; pre[k] = q.pre; isbg[k] = q.is_bg;
             c[k][0] = q.c[0]; c[k][1] = q.c[1]; c[k][2] = q.c[2];
         }
@@ -217,21 +217,34 @@ __global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restri
     }
 }
 
-extern "C" int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
-                                    const float* d_rgb, int64_t n_rays, int n_samples, int white_background, float* d_raw,
-                                    nf_stream_t stream) {
-    if (!raw || !z || !rd || !d_rgb || !d_raw || n_rays < 0 || n_samples <= 0 || n_samples > 64 * NF_MAX_CHUNKS) return NF_EINVAL;
+static int nf_volume_render_bwd_impl(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
+                                     const float* d_rgb, int64_t n_rays, int n_samples, int white_background, float* d_raw,
+                                     int mode, nf_stream_t stream) {
+    if (!raw || !z || (!rd && (mode & 1)) || !d_rgb || !d_raw || n_rays < 0 || n_samples <= 0 || n_samples > 64 * NF_MAX_CHUNKS) return NF_EINVAL;
     if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     const int nch = (n_samples + 63) / 64;
 #define NF_BWD(N)                                                                                                         \
     hipLaunchKernelGGL(k_volume_render_bwd<N>, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, z, rd, noise, bg,   \
-                       d_rgb, n_rays, n_samples, white_background, d_raw)
+                       d_rgb, n_rays, n_samples, white_background, d_raw, mode)
     if (nch == 1) NF_BWD(1); else if (nch == 2) NF_BWD(2); else if (nch == 3) NF_BWD(3); else if (nch == 4) NF_BWD(4);
     else if (nch <= 8) NF_BWD(8); else NF_BWD(16);
 #undef NF_BWD
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_volume_render_bwd(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
+                                    const float* d_rgb, int64_t n_rays, int n_samples, int white_background, float* d_raw,
+                                    nf_stream_t stream) {
+    return nf_volume_render_bwd_impl(raw, z, rd, noise, bg, d_rgb, n_rays, n_samples, white_background, d_raw, NF_VR_NERFACE, stream);
+}
+
+// Backward of tiny_nerf's render_volume_density (tiny_nerf.py:68-107) w.r.t. the radiance field, for the rgb output (the only
+// one the tiny trainer's loss reads, tiny_nerf.py:291-302): d_rgb (n_rays, 3) -> d_raw (n_rays, n_samples, 4).
+extern "C" int nf_render_volume_density_bwd(const float* raw, const float* depth, const float* d_rgb, int64_t n_rays, int n_samples,
+                                            float* d_raw, nf_stream_t stream) {
+    return nf_volume_render_bwd_impl(raw, depth, nullptr, nullptr, nullptr, d_rgb, n_rays, n_samples, 0, d_raw, NF_VR_TINY, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

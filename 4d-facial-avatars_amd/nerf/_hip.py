@@ -82,6 +82,15 @@ _PROTOTYPES = {
     "nf_tiny_pack": (C.c_int, [_P, _P, _P]),
     "nf_tiny_mlp_fwd": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _P, _P]),
     "nf_render_volume_density": (C.c_int, [_P, _P, _L, _I, _P, _P, _P, _P]),
+    "nf_tiny_saved_floats": (_Z, [_L]),
+    "nf_tiny_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
+    "nf_render_volume_density_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _P]),
+    "nf_tiny_packed_bwd_floats": (_Z, []),
+    "nf_tiny_pack_bwd": (C.c_int, [_P, _P, _P]),
+    "nf_tiny_grad_floats": (_Z, []),
+    "nf_tiny_bwd_workspace_floats": (_Z, [_L]),
+    "nf_tiny_mlp_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _Z, _P, _P]),
+    "nf_selftest_dw_tables_tiny": (C.c_int, []),
     "nf_volume_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "nf_volume_render_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "nf_sample_pdf": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),

@@ -3,8 +3,9 @@
 on libnerface_hip.so.  Reference citations: TN = tiny_nerf.py of gafniguy/4D-Facial-Avatars.
 
 The forward pass (what TN:111-159 computes) is one fused HIP kernel for query points + positional encoding + the
-3-layer MLP (nf_tiny_mlp_fwd) and one for the compositing (nf_render_volume_density).  Training tiny_nerf (autograd through
-these kernels) is not provided: the product's training path is the NeRFace trainer (nerf.run_one_iter_of_nerf).
+3-layer MLP (nf_tiny_mlp_fwd) and one for the compositing (nf_render_volume_density).  With gradients enabled the same
+call is differentiable w.r.t. the six model parameters (the reference script is a trainer, TN:282-302): the training
+forward saves PE / h1 / h2, and the backward runs nf_render_volume_density_bwd + nf_tiny_mlp_bwd (exact f32).
 """
 from __future__ import annotations
 
@@ -80,8 +81,69 @@ class VeryTinyNerfModel(torch.nn.Module):
             self._sig = sig
         return self._packed
 
+    def hip_packed_t(self):
+        """Transposed fragment image of layer2 / layer3 for the backward chain (cached like hip_packed)."""
+        ps = [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        if getattr(self, "_packed_t", None) is None or sig != getattr(self, "_sig_t", None):
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            self._packed_t = torch.empty(lib.nf_tiny_packed_bwd_floats(), dtype=torch.float32, device=dev)
+            arr = (C.c_void_p * 6)(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_tiny_pack_bwd(arr, H.ptr(self._packed_t), H.stream_ptr(dev)), "nf_tiny_pack_bwd")
+            self._sig_t = sig
+        return self._packed_t
+
     def forward(self, x):
         raise NotImplementedError("VeryTinyNerfModel is evaluated inside the fused kernel: call run_one_iter_of_tinynerf(...)")
+
+
+class _TinyRender(torch.autograd.Function):
+    """rgb (n_rays, 3) = render_volume_density(VeryTinyNerfModel(PE(ro + rd * depth))) with gradients for the six parameters
+    (TN:111-159 under autograd).  Ray origins / directions / depths carry no gradient (nothing upstream is learnable)."""
+
+    @staticmethod
+    def forward(ctx, model, ro, rd, depth, n_samples, *params):
+        dev = ro.device
+        n = ro.shape[0]
+        lib = H.lib()
+        raw = torch.empty((n, n_samples, 4), dtype=torch.float32, device=dev)
+        saved = torch.empty(lib.nf_tiny_saved_floats(n * n_samples), dtype=torch.float32, device=dev)
+        rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+        dmap = torch.empty((n,), dtype=torch.float32, device=dev)
+        acc = torch.empty((n,), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_tiny_mlp_fwd_train(H.ptr(model.hip_packed()), H.ptr(ro), H.ptr(rd), H.ptr(depth), 1, n, n_samples, H.ptr(raw),
+                                              H.ptr(saved), H.stream_ptr(dev)), "nf_tiny_mlp_fwd_train")
+            H.check(lib.nf_render_volume_density(H.ptr(raw), H.ptr(depth), n, n_samples, H.ptr(rgb), H.ptr(dmap), H.ptr(acc),
+                                                 H.stream_ptr(dev)), "nf_render_volume_density")
+        ctx.model, ctx.n_samples = model, n_samples
+        ctx.save_for_backward(raw, depth, saved)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        raw, depth, saved = ctx.saved_tensors
+        model, n_samples = ctx.model, ctx.n_samples
+        dev = raw.device
+        n = raw.shape[0]
+        lib = H.lib()
+        d_rgb = _c(d_rgb)
+        d_raw = torch.empty_like(raw)
+        ws_n = lib.nf_tiny_bwd_workspace_floats(n * n_samples)
+        ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
+        flat = torch.empty(lib.nf_tiny_grad_floats(), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_render_volume_density_bwd(H.ptr(raw), H.ptr(depth), H.ptr(d_rgb), n, n_samples, H.ptr(d_raw), H.stream_ptr(dev)),
+                    "nf_render_volume_density_bwd")
+            H.check(lib.nf_tiny_mlp_bwd(H.ptr(model.hip_packed_t()), H.ptr(saved), H.ptr(d_raw), n, n_samples, H.ptr(ws), ws_n, H.ptr(flat),
+                                        H.stream_ptr(dev)), "nf_tiny_mlp_bwd")
+        grads, off = [], 0
+        for p in (model.layer1.weight, model.layer1.bias, model.layer2.weight, model.layer2.bias, model.layer3.weight, model.layer3.bias):
+            grads.append(flat[off:off + p.numel()].view(p.shape))
+            off += p.numel()
+        return (None, None, None, None, None, *grads)
 
 
 def run_one_iter_of_tinynerf(height, width, focal_length, tform_cam2world, near_thresh, far_thresh, depth_samples_per_ray,
@@ -90,14 +152,16 @@ def run_one_iter_of_tinynerf(height, width, focal_length, tform_cam2world, near_
     compatibility -- encoding and chunking happen inside the fused kernel).  Returns rgb_predicted (H, W, 3)."""
     if not isinstance(model, VeryTinyNerfModel) or not model.fused_supported() or int(encoding_function_args) != 10:
         raise NotImplementedError("the fused tiny kernel is built for VeryTinyNerfModel(128, num_encoding_functions=10)")
-    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-        raise NotImplementedError("tiny_nerf training is not provided by the MI355X build; wrap inference in torch.no_grad()")
     ray_origins, ray_directions = get_ray_bundle(height, width, focal_length, tform_cam2world)
     depth_values = _depths(ray_origins, near_thresh, far_thresh, depth_samples_per_ray, True)       # default randomize=True
     dev = ray_origins.device
     ro, rd = ray_origins.reshape(-1, 3), ray_directions.reshape(-1, 3)
     depth = _c(depth_values.reshape(-1, depth_samples_per_ray))
     n = ro.shape[0]
+    if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
+        ps = (model.layer1.weight, model.layer1.bias, model.layer2.weight, model.layer2.bias, model.layer3.weight, model.layer3.bias)
+        rgb = _TinyRender.apply(model, _c(ro), _c(rd), depth, int(depth_samples_per_ray), *ps)
+        return rgb.reshape(height, width, 3)
     raw = torch.empty((n, depth_samples_per_ray, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         H.check(H.lib().nf_tiny_mlp_fwd(H.ptr(model.hip_packed()), H.ptr(_c(ro)), H.ptr(_c(rd)), H.ptr(depth), 1, n,

@@ -323,8 +323,30 @@ def bench_tiny(dev, steps=20):
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / steps
     assert rgb.shape == (64, 64, 3) and bool(torch.isfinite(rgb).all())
+    # the reference script is a trainer (TN:282-302): forward + mse + backward + Adam on the same image
+    target = torch.rand((64, 64, 3), generator=torch.Generator().manual_seed(13)).to(dev)
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3)
+
+    def train_once():
+        rgb = TN.run_one_iter_of_tinynerf(64, 64, focal, pose_d, 2.0, 6.0, 32, None, TN.get_minibatches, 16384, model, 10)
+        loss = torch.nn.functional.mse_loss(rgb, target)
+        loss.backward()
+        opt.step()
+        opt.zero_grad()
+        return loss
+    for _ in range(3):
+        train_once()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = train_once()
+    torch.cuda.synchronize()
+    ms_train = 1e3 * (time.perf_counter() - t0) / steps
+    assert bool(torch.isfinite(loss))
     res = {"workload": "configs[0]: tiny_nerf 64x64 image, 32 samples per ray, VeryTinyNerfModel (63-128-128-4), forward",
            "value": 4096 / (ms * 1e-3), "unit": "rays/s", "ms_per_image": ms, "images": steps,
+           "train": {"ms_per_iter": ms_train, "value": 4096 / (ms_train * 1e-3), "unit": "rays/s",
+                     "what": "forward + mse + backward (HIP kernels) + Adam per 64x64 image (TN:282-302)"},
            "note": "host-launch bound on the device (ray bundle + two kernels per image of 4096 rays)"}
     return res, ({k: v.detach().cpu() for k, v in model.state_dict().items()}, pose, focal)
 

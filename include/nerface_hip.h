@@ -197,6 +197,24 @@ int nf_tiny_mlp_fwd(const float* packed, const float* ro, const float* rd, const
 int nf_render_volume_density(const float* raw, const float* depth, int64_t n_rays, int n_samples, float* rgb,
                              float* depth_map, float* acc, nf_stream_t stream);
 
+/* ---- training the tiny path: autograd of run_one_iter_of_tinynerf (tiny_nerf.py:111-159) under the trainer's rgb loss
+ *      (tiny_nerf.py:291-302), exact f32.  nf_tiny_mlp_fwd_train also writes the activations the backward needs (`saved`,
+ *      nf_tiny_saved_floats(n_points) floats); nf_render_volume_density_bwd turns d loss / d rgb (R,3) into d_raw (R,S,4);
+ *      nf_tiny_mlp_bwd turns d_raw into the six parameter gradients, concatenated in state_dict order
+ *      [layer1.weight (128,63) | layer1.bias | layer2.weight | layer2.bias | layer3.weight (4,128) | layer3.bias]
+ *      (nf_tiny_grad_floats() floats).  packed_t = nf_tiny_pack_bwd (transposed fragment image of layer2 / layer3).       */
+size_t nf_tiny_saved_floats(int64_t n_points);
+int nf_tiny_mlp_fwd_train(const float* packed, const float* ro, const float* rd, const float* depth, int depth_per_ray,
+                          int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
+int nf_render_volume_density_bwd(const float* raw, const float* depth, const float* d_rgb, int64_t n_rays, int n_samples,
+                                 float* d_raw, nf_stream_t stream);
+size_t nf_tiny_packed_bwd_floats(void);
+int nf_tiny_pack_bwd(const float* const* params, float* packed_t, nf_stream_t stream);
+size_t nf_tiny_grad_floats(void);
+size_t nf_tiny_bwd_workspace_floats(int64_t n_points);
+int nf_tiny_mlp_bwd(const float* packed_t, const float* saved, const float* d_raw, int64_t n_rays, int n_samples,
+                    float* workspace, size_t workspace_floats, float* grads, nf_stream_t stream);
+
 /* ---- eval post-processing on the device -- replaces cast_to_image (eval_transformed_rays.py:184-190) and
  *      torch_normal_map(depthmap, focal, weights, clean=True) (eval_transformed_rays.py:84-119) ------------------------
  * rgb (H,W,3) -> rgb_u8 (H,W,3) = uint8(clamp(x,0,1)*255);  depthmap (H,W) [+ weights (H,W)] -> normals_u8 (H-1,W-1,3).
@@ -243,6 +261,7 @@ int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_str
 int nf_selftest_dw_tables_f32(void);
 int nf_selftest_dw_tables_lcode_f32(void);
 int nf_selftest_dw_tables_bf16(void);
+int nf_selftest_dw_tables_tiny(void);
 /* gather tables of the four split-bf16 weight streams (host code; out == NULL: number of entries): one code per element of
  * the hi blocks, tensor id << 24 | element offset, 0xFF000000 = zero padding                                            */
 long nf_paper_stream_table_bf16(uint32_t* out, size_t n_entries);

@@ -152,6 +152,36 @@ def make_load_flame():
     np.savez_compressed(os.path.join(OUT, "load_flame.npz"), **blob)
 
 
+def make_tiny_grads(ref):
+    """One training step of the UNMODIFIED tiny_nerf.py (TN:282-302): rgb = run_one_iter_of_tinynerf(...), loss = mse(rgb, target),
+    loss.backward() -- loss and the six parameter gradients (64x64 image, 32 samples, injected jitter)."""
+    TN = RI.import_reference_tiny()
+    tp = O.tiny_init_params(9458)
+    tm = TN.VeryTinyNerfModel(num_encoding_functions=10)
+    tm.load_state_dict(tp)
+    pose = O.frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    jit = torch.rand((64, 64, 32), generator=torch.Generator().manual_seed(77))
+    target = O.synthetic_image(64, 64, 13)
+    with RI.injected_random([jit], []):
+        rgb = TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, lambda x, n: ref.positional_encoding(x, n),
+                                          ref.get_minibatches, 16384, tm, 10)
+    loss = torch.nn.functional.mse_loss(rgb, target)
+    loss.backward()
+    blob = {"loss": loss.detach().numpy(), "rgb": rgb.detach().numpy()}
+    for k, v in tm.named_parameters():
+        blob["grad:" + k] = v.grad.numpy()
+    # the oracle's autograd (fp32) on the same step
+    pp = {k: v.clone().requires_grad_(True) for k, v in tp.items()}
+    rgb2, _, _ = O.tiny_render(pp, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+    torch.nn.functional.mse_loss(rgb2, target).backward()
+    worst = max(float((pp[k].grad - torch.from_numpy(blob["grad:" + k])).norm() / (torch.from_numpy(blob["grad:" + k]).norm() + 1e-30)) for k in tp)
+    print("tiny grad fixture: loss", float(loss), "oracle-vs-reference worst rel L2", worst)
+    assert worst < 1e-5
+    np.savez_compressed(os.path.join(OUT, "tiny_grads.npz"), **blob)
+
+
 def make_pe_pdf(ref):
     """positional encoding + sample_pdf_2 (H:344-387) incl. edge cases.  The reference returns only the samples; the CDF
     table and the searchsorted indices stored next to them come from the oracle restatement AFTER it reproduced the
@@ -205,6 +235,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "pe_pdf":
         make_pe_pdf(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "tiny_grads":
+        make_tiny_grads(ref)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "eval_post":
         make_eval_post()
@@ -305,6 +338,7 @@ def main():
     make_pe_pdf(ref)
     make_eval_post()
     make_load_flame()
+    make_tiny_grads(ref)
 
     # tiny_nerf (BASELINE config 1): 64x64, 32 samples, 3-layer 128-wide MLP, coarse only
     TN = RI.import_reference_tiny()

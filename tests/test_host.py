@@ -175,6 +175,11 @@ def test_oracle_is_imported_only_by_the_checkers():
     assert len(pat.findall(bench)) == n_legs > 0
 
 
+def test_tiny_dw_job_table_selftest(hip_lib):
+    """Weight-gradient job table of the tiny path (three products): every slab entry written exactly once."""
+    assert hip_lib.nf_selftest_dw_tables_tiny() == 0
+
+
 def test_cfgnode_roundtrip():
     import yaml
     import nerf

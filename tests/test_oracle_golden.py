@@ -177,3 +177,19 @@ def test_gaussian_smoothing_keeps_the_reference_formula():
         ref = RI.import_reference()
         r = ref.GaussianSmoothing(3, 11, 2.0)
         assert torch.equal(r.weight, m.weight) and torch.equal(r(img), m(img))
+
+
+def test_tiny_gradient_fixture():
+    """Oracle autograd (fp32) of the tiny training step vs the reference's own autograd (tests/golden/tiny_grads.npz)."""
+    g = np.load(os.path.join(GOLD, "tiny_grads.npz"))
+    tp = {k: v.clone().requires_grad_(True) for k, v in O.tiny_init_params(9458).items()}
+    pose = O.frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    jit = torch.rand((64, 64, 32), generator=torch.Generator().manual_seed(77))
+    rgb, _, _ = O.tiny_render(tp, 64, 64, torch.tensor(138.88 * 64 / 100.0), pose, 2.0, 6.0, 32, 10, jitter=jit)
+    loss = torch.nn.functional.mse_loss(rgb, O.synthetic_image(64, 64, 13))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss"])) < 1e-6
+    for k, v in tp.items():
+        want = torch.from_numpy(g["grad:" + k])
+        assert float((v.grad - want).norm() / (want.norm() + 1e-30)) < 1e-5, k
