@@ -44,6 +44,8 @@ static void nf_lcode_table_bf16(std::vector<uint32_t>& t) {
                     }
 }
 
+void nf_lcode_table_bf16_shared(std::vector<uint32_t>& t) { nf_lcode_table_bf16(t); }        // also the split-fp16 stream's table
+
 static NfPackTable g_lcode_table_b;
 
 extern "C" size_t nf_lcode_packed_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }

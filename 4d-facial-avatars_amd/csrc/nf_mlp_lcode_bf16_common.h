@@ -4,7 +4,19 @@
 #include "nf_common.h"
 #include "nf_mlp_lcode_layout.h"
 
+// element type of the split operands: bf16 pairs, or (NFB_F16 = 1, nf_mlp_lcode_f16.hip) fp16 pairs -- see nf_mlp_bf16_common.h
+#ifndef NFB_F16
+#define NFB_F16 0
+#endif
+#if NFB_F16
+typedef _Float16 nfb_elt;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#else
+typedef __bf16 nfb_elt;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 

@@ -163,14 +163,6 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             self.fc_out = torch.nn.Linear(hidden_size, 4)
         self.relu = torch.nn.functional.relu
         self.sigmoid = torch.sigmoid
-        self._packed = None
-        self._sig = None
-        self._packed_t = None
-        self._sig_t = None
-        self._packed_b = None
-        self._sig_b = None
-        self._packed_bt = None
-        self._sig_bt = None
 
     def fused_supported(self) -> bool:
         return (self.use_viewdirs and self.dim_xyz == 63 and self.dim_dir == 24 and self.dim_expression == 76
@@ -181,65 +173,75 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         sd = dict(self.named_parameters())
         return [sd[k] for k in LCODE_KEYS]
 
+    # one cached image per kind: (size function, pack function, element dtype); rebuilt when a parameter's version moves
+    _PACK_KINDS = {
+        "f32": ("nf_lcode_packed_floats", "nf_lcode_pack", torch.float32),
+        "f32_t": ("nf_lcode_packed_bwd_floats", "nf_lcode_pack_bwd", torch.float32),
+        "bf16": ("nf_lcode_packed_bf16_bytes", "nf_lcode_pack_bf16", torch.uint8),
+        "bf16_t": ("nf_lcode_packed_bwd_bf16_bytes", "nf_lcode_pack_bwd_bf16", torch.uint8),
+        "f16": ("nf_lcode_packed_f16_bytes", "nf_lcode_pack_f16", torch.uint8),
+    }
+
+    def _hip_pack(self, kind):
+        import ctypes as C
+        from . import _hip as H
+        ps = self.hip_param_list()
+        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        cache = self.__dict__.setdefault("_pack_cache", {})
+        hit = cache.get(kind)
+        if hit is None or hit[0] != sig:
+            size_fn, pack_fn, dtype = self._PACK_KINDS[kind]
+            dev = H.require_device(*[p.detach() for p in ps])
+            lib = H.lib()
+            buf = hit[1] if hit is not None and hit[1].device == dev else torch.empty(getattr(lib, size_fn)(), dtype=dtype, device=dev)
+            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+            with torch.cuda.device(dev):
+                H.check(getattr(lib, pack_fn)(arr, H.ptr(buf), H.stream_ptr(dev)), pack_fn)
+            cache[kind] = (sig, buf)
+        return cache[kind][1]
+
     def _hip_packed(self):
-        import ctypes as C
-        from . import _hip as H
-        ps = self.hip_param_list()
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if self._packed is None or sig != self._sig:
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed = torch.empty(lib.nf_lcode_packed_floats(), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_lcode_pack(arr, H.ptr(self._packed), H.stream_ptr(dev)), "nf_lcode_pack")
-            self._sig = sig
-        return self._packed
-
-    def _hip_packed_bf16(self):
-        import ctypes as C
-        from . import _hip as H
-        ps = self.hip_param_list()
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if self._packed_b is None or sig != self._sig_b:
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed_b = torch.empty(lib.nf_lcode_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_lcode_pack_bf16(arr, H.ptr(self._packed_b), H.stream_ptr(dev)), "nf_lcode_pack_bf16")
-            self._sig_b = sig
-        return self._packed_b
-
-    def _hip_packed_bf16_t(self):
-        import ctypes as C
-        from . import _hip as H
-        ps = self.hip_param_list()
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if self._packed_bt is None or sig != self._sig_bt:
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed_bt = torch.empty(lib.nf_lcode_packed_bwd_bf16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_lcode_pack_bwd_bf16(arr, H.ptr(self._packed_bt), H.stream_ptr(dev)), "nf_lcode_pack_bwd_bf16")
-            self._sig_bt = sig
-        return self._packed_bt
+        return self._hip_pack("f32")
 
     def _hip_packed_t(self):
-        import ctypes as C
-        from . import _hip as H
-        ps = self.hip_param_list()
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if self._packed_t is None or sig != self._sig_t:
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed_t = torch.empty(lib.nf_lcode_packed_bwd_floats(), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_lcode_pack_bwd(arr, H.ptr(self._packed_t), H.stream_ptr(dev)), "nf_lcode_pack_bwd")
-            self._sig_t = sig
-        return self._packed_t
+        return self._hip_pack("f32_t")
+
+    def _hip_packed_bf16(self):
+        return self._hip_pack("bf16")
+
+    def _hip_packed_bf16_t(self):
+        return self._hip_pack("bf16_t")
+
+    def hip_weights(self):
+        """The interface ops.check_f16_range polls (range-guard flag of the split-fp16 stream)."""
+        model = self
+
+        class _W:
+            def f16_range_flag(self):
+                from . import _hip as H
+                hit = model.__dict__.get("_pack_cache", {}).get("f16")
+                if hit is None:
+                    return None
+                off = H.lib().nf_lcode_f16_flag_offset()
+                return hit[1][off:off + 4].view(torch.int32)[0]
+        return _W()
+
+    def _f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far, max_rays=256, max_samples=8):
+        """Range probe for the split-fp16 kernel (cf. ops.f16_preflight): the exact-f32 training forward on a strided sample of
+        the chunk's points; returns the largest hidden |activation|."""
+        n_rays, n_s = z.shape
+        rs, ss = max(1, n_rays // max_rays), max(1, n_s // max_samples)
+        rv = None if rd_view is None else rd_view[::rs].contiguous()
+        keep = ops.get_mlp_precision()
+        ops.set_mlp_precision("f32")
+        try:
+            with torch.enable_grad():
+                _, state = self.hip_forward(ro[::rs].contiguous(), rd[::rs].contiguous(), z[::rs, ::ss].contiguous(), rv, expr, latent, near, far, True)
+        finally:
+            ops.set_mlp_precision(keep)
+        saved = state[2]
+        n = z[::rs, ::ss].numel()
+        return float(saved[64 * n:1472 * n].abs().max().item())     # sections S_L1 .. S_DIR (csrc/nf_mlp_lcode_layout.h)
 
     def hip_forward(self, ro, rd, z, rd_view, expr, latent, near, far, need_grad):
         import numpy as np
@@ -254,15 +256,25 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             H.check(lib.nf_lcode_condition(H.ptr(packed), H.ptr(expr), H.ptr(latent), float(np.float32(near)), float(np.float32(far)),
                                            H.ptr(cond), H.stream_ptr(dev)), "nf_lcode_condition")
             if not need_grad:
-                from . import ops
                 if ops.get_mlp_precision() == "bf16x3":
                     H.check(lib.nf_lcode_mlp_fwd_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
                                                       H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_bf16")
+                elif ops.get_mlp_precision() == "f16x3":
+                    key = (tuple((int(p.data_ptr()), int(p._version)) for p in self.hip_param_list()), expr.data_ptr(), latent.data_ptr(),
+                           expr._version, latent._version)
+                    if getattr(self, "_f16_probe_key", None) != key:      # once per (weights, conditioning): once per frame and model
+                        amax = self._f16_preflight(ro, rd, z, rd_view, expr, latent, near, far)
+                        if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
+                            raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g} '
+                                               f'on a sample of this frame, within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit '
+                                               f'({ops.F16_ACT_LIMIT:g}) -- render this model with "f32" or "bf16x3"')
+                        self._f16_probe_key = key
+                    H.check(lib.nf_lcode_mlp_fwd_f16(H.ptr(self._hip_pack("f16")), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
+                                                     H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_f16")
                 else:
                     H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
                                                  n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
                 return raw, None
-            from . import ops
             split = ops.get_mlp_precision() == "bf16x3"
             saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
             if split:

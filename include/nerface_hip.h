@@ -159,6 +159,12 @@ int nf_lcode_pack_bf16(const float* const* params, void* packed_bf16, nf_stream_
 int nf_lcode_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd,
                           const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,
                           nf_stream_t stream);
+/* split-fp16 ("f16x3") forward of the second model family: contract, valid range and range guard as nf_paper_mlp_fwd_f16 */
+size_t nf_lcode_packed_f16_bytes(void);
+size_t nf_lcode_f16_flag_offset(void);
+int nf_lcode_pack_f16(const float* const* params, void* stream_out, nf_stream_t stream);
+int nf_lcode_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                         const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
 
 /* Training of the same family, exact f32 (autograd through M:590-636 as the trainer drives it, TR:355-392):
  * forward that also fills `saved` (nf_lcode_saved_floats(n_rays*n_samples) floats), transposed weight image, and the

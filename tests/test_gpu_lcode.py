@@ -217,3 +217,57 @@ def test_lcode_bf16x3_psnr_gate_and_golden(hip_lib, gpu):
         p_ref, p_our = O.psnr(torch.from_numpy(gold[name]), c["tgt"]), O.psnr(out[k].cpu(), c["tgt"])
         print(f"lcode bf16x3 {name}: PSNR ref {p_ref:.6f} ours {p_our:.6f} |d|={abs(p_ref - p_our):.2e} dB")
         assert abs(p_ref - p_our) <= 1e-4
+
+
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (40, 192)])
+def test_lcode_f16x3_mlp_meets_the_f32_gate(hip_lib, gpu, n_rays, s):
+    """Split-fp16 kernel of the second family: raw outputs against fp64 within the EXACT-f32 kernel's gate and within a small
+    factor of its error (fp32-class), far below the split-bf16 error."""
+    import nerf
+    c = C.build_case("eval_det_64_128")
+    g = torch.Generator().manual_seed(5)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 3, n_rays, 5)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    p = O.init_lcode_params(6)
+    m = lmodel(nerf, p, gpu)
+    args = (ro.to(gpu), rd.to(gpu), z.to(gpu), rd.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR, False)
+    out = {}
+    for prec in ("f32", "f16x3", "bf16x3"):
+        nerf.set_mlp_precision(prec)
+        out[prec] = m.hip_forward(*args)[0].cpu()
+    nerf.set_mlp_precision("f32")
+    p64 = {k: v.double() for k, v in p.items()}
+    ref = O.lcode_mlp(p64, O.encode_points(ro.double(), rd.double(), z.double(), O.NEAR, O.FAR), c["expr"].double(),
+                      c["latent"].double()).reshape(n_rays, s, 4)
+    scale = ref.abs().amax(dim=(0, 1))
+    err = {k: (v.double() - ref).abs().amax(dim=(0, 1)) for k, v in out.items()}
+    rms = {k: (v.double() - ref).pow(2).mean(dim=(0, 1)).sqrt() for k, v in out.items()}
+    print(f"lcode f16x3 max err {err['f16x3'].tolist()}  f32 {err['f32'].tolist()}  bf16x3 {err['bf16x3'].tolist()}  scale {scale.tolist()}")
+    assert torch.all(err["f16x3"] <= 2e-5 * scale + 2e-5)
+    assert torch.all(rms["f16x3"] <= 4.0 * rms["f32"] + 1e-9)
+
+
+def test_lcode_f16x3_end_to_end_at_f32_tolerances(hip_lib, gpu):
+    import nerf
+    gold = np.load(os.path.join(GOLD, "lcode_eval_det_64_128.npz"))
+    c = C.build_case("eval_det_64_128")
+    mc, mf = lmodel(nerf, O.init_lcode_params(5), gpu), lmodel(nerf, O.init_lcode_params(6), gpu)
+    opt = U.make_options(nerf, 64, 128, False, 0.0)
+    ex, ed = U.encoders(nerf)
+    nerf.set_mlp_precision("f16x3")
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train",
+                                        encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                        background_prior=c["bg"].to(gpu), latent_code=c["latent"].to(gpu))
+    for n, t in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"], out):
+        d = np.abs(t.cpu().numpy() - gold[n])
+        print(f"[lcode f16x3] {n}: max|d|={d.max():.3e}")
+        assert d.max() <= TOL[n], (n, d.max())
+    # range guard of this family: blown-up hidden weights are refused by the pre-flight probe
+    pbad = dict(O.init_lcode_params(5))
+    pbad["layers_xyz.1.weight"] = pbad["layers_xyz.1.weight"] * 2.0 ** 14
+    mb = lmodel(nerf, pbad, gpu)
+    with pytest.raises(RuntimeError, match="fp16 range"), torch.no_grad():
+        nerf.run_one_iter_of_nerf(512, 512, None, mb, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train", encode_position_fn=ex,
+                                  encode_direction_fn=ed, expressions=c["expr"].to(gpu), background_prior=c["bg"].to(gpu),
+                                  latent_code=c["latent"].to(gpu))
