@@ -22,8 +22,16 @@
 #include <mutex>
 #include <vector>
 
+// NFB_F16 = 1 (nf_mlp_f16_dw.hip includes this file): the same kernel on fp16 operand pairs.  Saved activations are converted
+// times 2^4 and gradients times the per-launch power of two G of the backward chain (gscale = {G, 1 / G}, nf_pack.h), so that
+// both sit inside fp16's exponent range; the accumulators are multiplied by 1 / (16 G) before they go to the slab.
 #include "nf_mlp_bf16_common.h"
 #include "nf_mlp_lcode_layout.h"
+#if NFB_F16
+#define NFB_DW_NAME(x) x##_f16
+#else
+#define NFB_DW_NAME(x) x##_bf16
+#endif
 
 struct NfbDwSeg {
     int kind;      // 0: dz section, 1: d_raw, 2: saved section
@@ -53,8 +61,8 @@ struct NfbDwJob {
 #define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
 #define NFB_DW_NSET 3                                    // register sets of raw tiles: NSET - 1 stages of loads in flight
 #define NFB_DW_CVT_U4 (NFB_DW_MAX_TILES * 128)           // 16-byte units: per tile 64 lanes x (hi, lo)
-__constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
-__constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
+static __constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
+static __constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
 
 // job-table builder helpers (host)
 struct NfbDwBuilder {
@@ -207,9 +215,9 @@ static void nfb_build_dw_jobs(NfbDwJob* jobs) {
 __device__ __forceinline__ void nfb_dw_split(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const __bf16 hh = (__bf16)x[j];
+        const nfb_elt hh = (nfb_elt)x[j];
         hi[j] = hh;
-        lo[j] = (__bf16)(x[j] - (float)hh);
+        lo[j] = (nfb_elt)(x[j] - (float)hh);
     }
 }
 
@@ -235,8 +243,9 @@ __device__ __forceinline__ void nfb_dw_load_tail(__amdgpu_buffer_rsrc_t rsrc, un
 // MODEL selects the job table: 0 paper model, 1 second model family
 template <int MODEL>
 __global__ void __launch_bounds__(64 * NFB_DW_WAVES, 1)
-k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
-                     int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs, int slab_floats) {
+NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
+                             int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs, int slab_floats,
+                             const float* __restrict__ gscale) {
     __shared__ __attribute__((aligned(16))) uint4 lds_cvt[2 * NFB_DW_CVT_U4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
@@ -259,6 +268,10 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(t_g), (short)0, (int)(n_stages * NFB_DW_PTS * t_stride_b), 0x00020000);
     const unsigned t_voff = (t_on && t_fok) ? 4u * (unsigned)(tl.f0 + c) + (unsigned)(8 * h) * t_stride_b : 0x80000000u;
+#if NFB_F16
+    const float t_scale = tsg.kind == 2 ? 16.0f : gscale[0];          // activations x 2^4, gradients x G (exact powers of two)
+    const float out_scale = gscale[1] * (1.0f / 16.0f);
+#endif
     float t_cs = 0.f;
     float xs[NFB_DW_NSET][8];
     auto load = [&](int i, float (&x)[8]) { nfb_dw_load(t_rsrc, t_voff + (unsigned)i * NFB_DW_PTS * t_stride_b, t_stride_b, x); };
@@ -286,7 +299,14 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
         __builtin_amdgcn_sched_barrier(0);
         {
             bf16x8 hi, lo;
+#if NFB_F16
+            float xsc[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xsc[j] = xc[j] * t_scale;
+            nfb_dw_split(xsc, hi, lo);
+#else
             nfb_dw_split(xc, hi, lo);
+#endif
             t_cs += ((xc[0] + xc[1]) + (xc[2] + xc[3])) + ((xc[4] + xc[5]) + (xc[6] + xc[7]));
             wr[0] = __builtin_bit_cast(uint4, hi);
             wr[64] = __builtin_bit_cast(uint4, lo);
@@ -297,12 +317,12 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) acc[t][u] = NFB_MFMA(ah[t], bh[u], acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) acc[t][u] = NFB_MFMA(ah[t], bl[u], acc[t][u], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) al[t] = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
@@ -311,7 +331,7 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], bh[u], acc[t][u], 0, 0, 0);
+            for (int u = 0; u < 2; ++u) acc[t][u] = NFB_MFMA(al[t], bh[u], acc[t][u], 0, 0, 0);
         __syncthreads();
     };
 
@@ -330,7 +350,14 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
         float xt[8];
         nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
         bf16x8 hi, lo;
+#if NFB_F16
+        float xsc[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xsc[j] = xt[j] * t_scale;
+        nfb_dw_split(xsc, hi, lo);
+#else
         nfb_dw_split(xt, hi, lo);
+#endif
         t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
         lds_cvt[wave * 128 + lane] = __builtin_bit_cast(uint4, hi);
         lds_cvt[wave * 128 + lane + 64] = __builtin_bit_cast(uint4, lo);
@@ -342,9 +369,9 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
             for (int u = 0; u < 2; ++u) {
                 const bf16x8 ah = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128]), al = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
                 const bf16x8 bh = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + u) * 128]), bl = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + u) * 128 + 64]);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[t][u], 0, 0, 0);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[t][u], 0, 0, 0);
-                acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[t][u], 0, 0, 0);
+                acc[t][u] = NFB_MFMA(ah, bh, acc[t][u], 0, 0, 0);
+                acc[t][u] = NFB_MFMA(ah, bl, acc[t][u], 0, 0, 0);
+                acc[t][u] = NFB_MFMA(al, bh, acc[t][u], 0, 0, 0);
             }
     }
 
@@ -358,7 +385,11 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
             if (row >= pr.a_valid) continue;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
+#if NFB_F16
+                if (32 * u + c < pr.b_valid) slab[pr.out_off + row * pr.ldo + 32 * u + c] = acc[t][u][r] * out_scale;
+#else
                 if (32 * u + c < pr.b_valid) slab[pr.out_off + row * pr.ldo + 32 * u + c] = acc[t][u][r];
+#endif
         }
     }
     if (t_on && tl.cs_off >= 0) {
@@ -370,9 +401,10 @@ k_paper_dw_gemm_bf16(const float* __restrict__ dz, const float* __restrict__ d_r
 static std::mutex g_dwb_mutex;
 static bool g_dwb_ready[64] = {false};
 
-// called by nf_paper_mlp_bwd_bf16 (nf_mlp_bwd.hip) / nf_lcode_mlp_bwd_bf16; slabs: n_slices x slab floats of the model
-int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
-                       int n_slices, float* slabs, nf_stream_t stream) {
+// called by nf_paper_mlp_bwd_bf16 / _f16 (nf_mlp_bwd.hip) and the lcode counterparts; slabs: n_slices x slab floats of the model;
+// gscale: device {G, 1 / G} (fp16 instantiation only)
+int NFB_DW_NAME(nfb_launch_dw_gemm)(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points,
+                                    int64_t pts_per_slice, int n_slices, float* slabs, const float* gscale, nf_stream_t stream) {
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -390,13 +422,15 @@ int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const flo
         }
     }
     if (model == 0)
-        hipLaunchKernelGGL((k_paper_dw_gemm_bf16<0>), dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream), dz,
-                           d_raw, saved, n_points, pts_per_slice, slabs, (int)nfl::SLAB_FLOATS);
+        hipLaunchKernelGGL((NFB_DW_NAME(k_paper_dw_gemm)<0>), dim3(NFB_DW_JOBS, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0, nf_s(stream),
+                           dz, d_raw, saved, n_points, pts_per_slice, slabs, (int)nfl::SLAB_FLOATS, gscale);
     else
-        hipLaunchKernelGGL((k_paper_dw_gemm_bf16<1>), dim3(NFB_DW_JOBS_LCODE, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0,
-                           nf_s(stream), dz, d_raw, saved, n_points, pts_per_slice, slabs, (int)nlc::SLAB_FLOATS);
+        hipLaunchKernelGGL((NFB_DW_NAME(k_paper_dw_gemm)<1>), dim3(NFB_DW_JOBS_LCODE, (unsigned)n_slices), dim3(64 * NFB_DW_WAVES), 0,
+                           nf_s(stream), dz, d_raw, saved, n_points, pts_per_slice, slabs, (int)nlc::SLAB_FLOATS, gscale);
     NF_RETURN_LAUNCH();
 }
+
+#if !NFB_F16
 
 // slices for the split-bf16 dW kernel: one workgroup per CU (paper: 11 bundles x 23 slices = 253 workgroups, second family:
 // 8 x 32 = 256); two rounds (46 slices) measured 2 % slower end to end (twice the slab traffic), three rounds slower still
@@ -461,3 +495,4 @@ extern "C" int nf_selftest_dw_tables_bf16(void) {
     rc = nfb_check_tables(jobs_l, NFB_DW_JOBS_LCODE, nlc::SLAB_FLOATS, lcode);
     return rc ? rc - 100 : 0;
 }
+#endif

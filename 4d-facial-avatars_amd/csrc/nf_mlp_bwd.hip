@@ -249,29 +249,36 @@ extern "C" size_t nf_paper_grad_floats(void) { return (size_t)nfl::GRAD_FLOATS; 
 
 // defined in nf_mlp_bf16_dw.hip
 void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices);
-int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
-                       int n_slices, float* slabs, nf_stream_t stream);
+int nfb_launch_dw_gemm_bf16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                            int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
+int nfb_launch_dw_gemm_f16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                           int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
 
 extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
     nf_bwd_plan(n_points, &pps, &ns);
     nfb_dw_plan(0, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
-    return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS;
+    return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS + 16;      // + the gradient scale {G, 1/G, scratch}
 }
 
 static NfDwJobTable g_paper_jobs;
 
-// defined in nf_mlp_bf16_bwd.hip
-int nfb_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                         nf_stream_t stream);
+// defined in nf_mlp_bf16_bwd.hip / nf_mlp_f16_bwd.hip
+int nfb_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                              const float* gscale, nf_stream_t stream);
+int nfb_launch_bwd_chain_f16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                             const float* gscale, nf_stream_t stream);
 
-static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, bool split_dw, const float* cond,
-                       const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
+// packed_t (exact f32 chain) | packed_t_bf16 (split-bf16 chain) | packed_t_f16 (split-fp16 chain + dW): exactly one non-NULL
+static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const void* packed_t_f16, bool split_dw,
+                       const float* cond, const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
                        size_t workspace_floats, float* grads, nf_stream_t stream) {
     using namespace nfl;
-    if (!packed || (!packed_t && !packed_t_bf16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0)
+    if (!packed || (!packed_t && !packed_t_bf16 && !packed_t_f16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 ||
+        n_samples <= 0)
         return NF_EINVAL;
+    if (packed_t_f16) split_dw = true;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
     int dev = 0;
@@ -287,6 +294,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
+    float* gscale = workspace + nf_paper_bwd_workspace_floats(n_points) - 16;
     hipStream_t s = nf_s(stream);
     constexpr int NT = NF_MLP_NT;
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
@@ -294,15 +302,21 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     if (grid > 0x7fffffff) return NF_EINVAL;
     e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    if (packed_t_bf16) {
-        const int rc2 = nfb_launch_bwd_chain(packed_t_bf16, saved, d_raw, n_points, dz, stream);
+    if (packed_t_f16) {
+        int rc2 = nf_grad_scale(d_raw, n_points * 4, gscale, stream);
+        if (rc2) return rc2;
+        rc2 = nfb_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
+        if (rc2) return rc2;
+    } else if (packed_t_bf16) {
+        const int rc2 = nfb_launch_bwd_chain_bf16(packed_t_bf16, saved, d_raw, n_points, dz, nullptr, stream);
         if (rc2) return rc2;
     } else {
         hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
                            n_points, dz);
     }
     if (split_dw) {
-        const int rc3 = nfb_launch_dw_gemm(0, dz, d_raw, saved, n_points, pps, ns, slabs, stream);
+        const int rc3 = packed_t_f16 ? nfb_launch_dw_gemm_f16(0, dz, d_raw, saved, n_points, pps, ns, slabs, gscale, stream)
+                                     : nfb_launch_dw_gemm_bf16(0, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc3) return rc3;
     } else {
         hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
@@ -320,7 +334,8 @@ extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, cons
                                 const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
                                 float* grads, nf_stream_t stream) {
     if (!packed_t) return NF_EINVAL;
-    return nf_bwd_impl(packed, packed_t, nullptr, false, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+    return nf_bwd_impl(packed, packed_t, nullptr, nullptr, false, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads,
+                       stream);
 }
 
 // Same, with the dX chain (nf_mlp_bf16_bwd.hip) and, unless exact_dw, the weight-gradient GEMMs (nf_mlp_bf16_dw.hip) on the
@@ -329,8 +344,19 @@ extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_b
                                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
                                      float* grads, int exact_dw, nf_stream_t stream) {
     if (!packed_t_bf16) return NF_EINVAL;
-    return nf_bwd_impl(packed, nullptr, packed_t_bf16, exact_dw == 0, cond, saved, d_raw, n_rays, n_samples, workspace,
+    return nf_bwd_impl(packed, nullptr, packed_t_bf16, nullptr, exact_dw == 0, cond, saved, d_raw, n_rays, n_samples, workspace,
                        workspace_floats, grads, stream);
+}
+
+// Same on fp16 operand pairs ("f16x3": fp32-class accuracy at the split-bf16 speed): dX chain (nf_mlp_f16_bwd.hip) and weight-
+// gradient GEMMs (nf_mlp_f16_dw.hip), gradients scaled by a per-launch power of two chosen from max |d_raw|.  `saved` must
+// come from nf_paper_mlp_fwd_train_f16; packed_t_f16 from nf_paper_pack_bwd_f16.
+extern "C" int nf_paper_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* cond, const float* saved,
+                                    const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                    float* grads, nf_stream_t stream) {
+    if (!packed_t_f16) return NF_EINVAL;
+    return nf_bwd_impl(packed, nullptr, nullptr, packed_t_f16, true, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats,
+                       grads, stream);
 }
 
 // host-only self-test of the exact-f32 job table (tests/test_host.py)

@@ -1,0 +1,23 @@
+// Training (activation-saving) instantiation of the split-fp16 fused forward (see nf_mlp_f16.hip for the scheme); its own
+// translation unit like nf_mlp_bf16_train.hip.  `saved` receives the TRUE layer outputs (scales removed) in the layout the
+// weight-gradient kernels read, plus the ReLU bit masks the split backward chain reads.
+#define NFB_F16 1
+#ifndef NFB_TILE_GROUP
+#define NFB_TILE_GROUP 4
+#endif
+#ifndef NFB_ACT_SHIFT
+#define NFB_ACT_SHIFT 4
+#endif
+#include "nf_mlp_bf16_common.h"
+#include "nf_pack.h"
+
+#define NFB_SAVE 1
+#define NFB_KERNEL_NAME k_paper_mlp_fwd_f16_train
+#include "nf_mlp_bf16_kernel.inc"
+
+int nfh_launch_train(const char* wstream, const float* cond, const float* ro, const float* rd, const float* rd_view, const float* z,
+                     int64_t n_points, int n_samples, float* raw, float* saved, unsigned grid, nf_stream_t stream) {
+    hipLaunchKernelGGL(k_paper_mlp_fwd_f16_train, dim3(grid), dim3(256), 0, nf_s(stream), wstream, cond, ro, rd, rd_view, z, n_points,
+                       n_samples, raw, saved);
+    NF_RETURN_LAUNCH();
+}

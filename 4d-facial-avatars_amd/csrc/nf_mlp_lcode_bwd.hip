@@ -224,8 +224,8 @@ extern "C" size_t nf_lcode_grad_floats(void) { return (size_t)nlc::GRAD_FLOATS; 
 
 // defined in nf_mlp_bf16_dw.hip / nf_mlp_lcode_bf16_bwd.hip
 void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices);
-int nfb_launch_dw_gemm(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
-                       int n_slices, float* slabs, nf_stream_t stream);
+int nfb_launch_dw_gemm_bf16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                            int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
 int nfb_lcode_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
                                nf_stream_t stream);
 
@@ -268,7 +268,7 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     if (split) {
         int rc = nfb_lcode_launch_bwd_chain(packed_t_bf16, saved, d_raw, n_points, dz, stream);
         if (rc) return rc;
-        rc = nfb_launch_dw_gemm(1, dz, d_raw, saved, n_points, pps, ns, slabs, stream);
+        rc = nfb_launch_dw_gemm_bf16(1, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc) return rc;
     } else {
         hipLaunchKernelGGL((k_lcode_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);

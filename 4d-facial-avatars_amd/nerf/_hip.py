@@ -40,6 +40,10 @@ _PROTOTYPES = {
     "nf_paper_f16_flag_offset": (_Z, []),
     "nf_paper_pack_f16": (C.c_int, [_P, _P, _P]),
     "nf_paper_mlp_fwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_paper_mlp_fwd_train_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "nf_paper_packed_bwd_f16_bytes": (_Z, []),
+    "nf_paper_pack_bwd_f16": (C.c_int, [_P, _P, _P]),
+    "nf_paper_mlp_bwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_paper_mlp_fwd_train_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_paper_saved_floats": (_Z, [_L]),
     "nf_paper_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),

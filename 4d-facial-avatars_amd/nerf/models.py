@@ -75,9 +75,20 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         packed = hw.get()
         cond = ops.paper_condition(packed, expr, latent, near, far)
         if need_grad:
-            pb = hw.get_bf16() if ops.get_mlp_precision() == "bf16x3" else None
-            raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view, packed_b=pb)
-            return raw, (packed, cond, saved, pb is not None)
+            prec = ops.get_mlp_precision()
+            pb = hw.get_bf16() if prec == "bf16x3" else None
+            ph = hw.get_f16() if prec == "f16x3" else None
+            if ph is not None:
+                # range probe (see the inference branch): weights move every step, so probe the first call and every 128th
+                n_calls = self.__dict__["_f16_train_calls"] = self.__dict__.get("_f16_train_calls", 0) + 1
+                if n_calls % 128 == 1:
+                    amax = ops.f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far)
+                    if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
+                        raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g}, '
+                                           f'within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit ({ops.F16_ACT_LIMIT:g}) -- train '
+                                           f'this model with "f32" or "bf16x3"')
+            raw, saved = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view, packed_b=pb, packed_h=ph)
+            return raw, (packed, cond, saved, "f16" if ph is not None else pb is not None)
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
         if ops.get_mlp_precision() == "f16x3":

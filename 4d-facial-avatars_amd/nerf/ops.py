@@ -27,8 +27,9 @@ PAPER_KEYS = (
 # "bf16x3" = split-bf16, three bf16 MFMAs per product with f32 accumulation (~2^-16 relative per product, 3x faster).
 # The switch applies to inference AND to a training step: under "bf16x3" the training forward, the dX chain and the
 # weight-gradient GEMMs all run on the split-bf16 kernels (paper_mlp_bwd(..., exact_dw=True) keeps the dW GEMMs exact).
-# "f16x3" = split-fp16: the same three-MFMA scheme on fp16 pairs (22 operand bits, per-layer power-of-two weight scales):
-# fp32-class accuracy at the bf16x3 speed, inference only (a training step under "f16x3" runs the exact-f32 kernels).
+# "f16x3" = split-fp16: the same three-MFMA scheme on fp16 pairs (22 operand bits, per-layer power-of-two weight scales,
+# per-launch gradient scale): fp32-class accuracy at the bf16x3 speed, for inference and -- paper model -- for all three
+# training GEMM kernels (the second model family trains on the exact-f32 kernels under "f16x3").
 _VALID_PRECISIONS = ("f32", "bf16x3", "f16x3")
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
 
@@ -135,12 +136,27 @@ class PaperWeights:
         self._versions_bt = None
         self.packed_h = None            # (hi, lo) fp16 stream + per-layer scales for the split-fp16 forward
         self._versions_h = None
+        self.packed_ht = None           # transposed (hi, lo) fp16 stream + scales for the split-fp16 backward chain
+        self._versions_ht = None
 
     def invalidate(self) -> None:
         """Drop every cached image.  The caches follow in-place updates through the parameters' version counters
         (optimizer.step(), load_state_dict(), copy_ under no_grad); writes that bypass the counter -- through `p.data`, or by
         a collective -- are NOT seen: call this (or model.hip_weights().invalidate()) after such a write."""
-        self._versions = self._versions_t = self._versions_b = self._versions_bt = self._versions_h = None
+        self._versions = self._versions_t = self._versions_b = self._versions_bt = self._versions_h = self._versions_ht = None
+
+    def get_f16_t(self) -> torch.Tensor:
+        sig = self._signature()
+        if self.packed_ht is None or sig != self._versions_ht:
+            dev = H.require_device(*[p.detach() for p in self._params])
+            lib = H.lib()
+            if self.packed_ht is None or self.packed_ht.device != dev:
+                self.packed_ht = torch.empty(lib.nf_paper_packed_bwd_f16_bytes(), dtype=torch.uint8, device=dev)
+            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
+            with torch.cuda.device(dev):
+                H.check(lib.nf_paper_pack_bwd_f16(arr, H.ptr(self.packed_ht), H.stream_ptr(dev)), "nf_paper_pack_bwd_f16")
+            self._versions_ht = sig
+        return self.packed_ht
 
     def get_f16(self) -> torch.Tensor:
         sig = self._signature()
@@ -297,17 +313,21 @@ def check_f16_range(*models) -> None:
                            'finite -- render this model with "f32" or "bf16x3"')
 
 
-def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None):
+def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None, packed_h=None):
     """Training forward: returns (raw, (saved,)) where `saved` holds every layer output for the backward.
-    packed_b given -> the forward runs on the split-bf16 kernel and `saved` additionally carries its ReLU bit masks; the
-    matching backward is paper_mlp_bwd(..., split=True)."""
+    packed_b (split-bf16 stream) or packed_h (split-fp16 stream) given -> the forward runs on that split kernel and `saved`
+    additionally carries its ReLU bit masks; the matching backward is paper_mlp_bwd(..., split=True / "f16")."""
     dev = H.require_device(packed, cond, ro, rd, z, rd_view)
     n_rays, n_samples = z.shape
     lib = H.lib()
     raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
     saved = torch.empty(lib.nf_paper_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        if packed_b is not None:
+        if packed_h is not None:
+            H.check(lib.nf_paper_mlp_fwd_train_f16(H.ptr(packed_h), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                                   n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
+                    "nf_paper_mlp_fwd_train_f16")
+        elif packed_b is not None:
             H.check(lib.nf_paper_mlp_fwd_train_bf16(H.ptr(packed_b), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
                                                     n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
                     "nf_paper_mlp_fwd_train_bf16")
@@ -330,7 +350,11 @@ def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False, exact_dw=Fa
     ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
     flat = torch.empty(lib.nf_paper_grad_floats(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        if split:
+        if split == "f16":
+            packed_ht = model.hip_weights().get_f16_t()
+            H.check(lib.nf_paper_mlp_bwd_f16(H.ptr(packed), H.ptr(packed_ht), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
+                                             n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd_f16")
+        elif split:
             packed_bt = model.hip_weights().get_bf16_t()
             H.check(lib.nf_paper_mlp_bwd_bf16(H.ptr(packed), H.ptr(packed_bt), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
                                               n_samples, H.ptr(ws), ws_floats, H.ptr(flat), int(bool(exact_dw)), H.stream_ptr(dev)),

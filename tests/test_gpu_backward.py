@@ -144,6 +144,67 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s, split):
         assert rel_l2(g_lat.cpu(), g_lat_x.cpu()) < 1e-4
 
 
+@pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (37, 128)])
+def test_paper_mlp_bwd_f16x3(hip_lib, gpu, n_rays, s):
+    """The three training GEMM kernels on fp16 operand pairs: gradients against the fp64 oracle at the masks the HIP forward saw,
+    held to the EXACT-f32 kernels' gate (1e-4 per tensor) and compared with the f32 and split-bf16 kernels' own errors."""
+    import nerf
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    g = torch.Generator().manual_seed(13)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 9, n_rays, 13)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    d_raw = torch.randn((n_rays, s, 4), generator=g) * 1e-4          # realistic scale: d loss / d raw of a 2048-ray batch
+    p = c["p_fine"]
+    m = U.make_model(nerf, p, gpu)
+    hw = m.hip_weights()
+    pk = hw.get()
+    cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    dv = lambda t: t.to(gpu)
+    worst = {}
+    for mode in ("f32", "f16", "bf16"):
+        raw_t, saved = ops.paper_mlp_fwd_train(pk, cond, dv(ro), dv(rd), dv(z), packed_b=hw.get_bf16() if mode == "bf16" else None,
+                                               packed_h=hw.get_f16() if mode == "f16" else None)
+        if mode == "f16":
+            assert torch.equal(raw_t, ops.paper_mlp_fwd_f16(hw.get_f16(), cond, dv(ro), dv(rd), dv(z)))      # training forward == eval forward
+        grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, dv(z), dv(d_raw), saved, split={"f32": False, "f16": "f16", "bf16": True}[mode])
+        n_pts = n_rays * s
+        sv = saved[0].cpu()
+        masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
+        pp, lat, _ = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=masks)
+        w = 0.0
+        for k, gh in zip(ops.PAPER_KEYS, grads):
+            if k.startswith("layers_dir.3"):
+                assert gh is None
+                continue
+            w = max(w, rel_l2(gh.cpu(), pp[k].grad))
+        worst[mode] = (w, rel_l2(g_lat.cpu(), lat.grad))
+    print(f"mlp bwd ({n_rays}x{s}) worst param rel L2 / latent:  f32 {worst['f32'][0]:.2e} / {worst['f32'][1]:.2e}   "
+          f"f16x3 {worst['f16'][0]:.2e} / {worst['f16'][1]:.2e}   bf16x3 {worst['bf16'][0]:.2e} / {worst['bf16'][1]:.2e}")
+    assert worst["f16"][0] < 1e-4 and worst["f16"][1] < 1e-4
+    assert worst["f16"][0] < max(4.0 * worst["f32"][0], 5e-6)           # fp32-class: within a small factor of the exact-f32 kernels
+
+
+def test_train_step_f16x3_follows_the_f32_path(hip_lib, gpu):
+    """Whole training step (coarse + fine, noise, perturb, latent regulariser) under nerf.set_mlp_precision("f16x3") against the
+    same step on the exact-f32 kernels: loss and every gradient tensor."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    res = {}
+    for prec in ("f32", "f16x3"):
+        nerf.set_mlp_precision(prec)
+        out, mc, mf, latent = U.run_product(nerf, c, gpu, mode="train", grad=True)
+        loss = O.train_loss(out[0], out[3], c["tgt"].to(gpu), latent)
+        loss.backward()
+        res[prec] = (float(loss), {f"{t}.{k}": v.grad.clone() for t, m in (("c", mc), ("f", mf)) for k, v in m.named_parameters() if v.grad is not None},
+                     latent.grad.clone())
+    nerf.set_mlp_precision("f32")
+    assert abs(res["f32"][0] - res["f16x3"][0]) < 2e-6
+    worst = max(rel_l2(res["f16x3"][1][k], v) for k, v in res["f32"][1].items())
+    print(f"train step f16x3 vs f32 kernels: worst param rel L2 {worst:.2e}, latent {rel_l2(res['f16x3'][2], res['f32'][2]):.2e}")
+    assert worst < 1.5e-3 and rel_l2(res["f16x3"][2], res["f32"][2]) < 1e-4     # same end-to-end bound the f32 path has vs fp64 (ReLU flips)
+
+
 def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
     """Full training step (coarse+fine, noise, perturb, latent regulariser) through run_one_iter_of_nerf + autograd."""
     import nerf
