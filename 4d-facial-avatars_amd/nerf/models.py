@@ -92,7 +92,7 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
         if ops.get_mlp_precision() == "f16x3":
-            key = (hw._signature(), expr.data_ptr(), latent.data_ptr(), expr._version, latent._version)
+            key = (hw._signature()[1:], expr.data_ptr(), latent.data_ptr(), expr._version, latent._version)
             if getattr(self, "_f16_probe_key", None) != key:      # once per (weights, conditioning): i.e. once per frame and model
                 amax = ops.f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far)
                 if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
@@ -197,7 +197,7 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         import ctypes as C
         from . import _hip as H
         ps = self.hip_param_list()
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        sig = (ops.pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
         cache = self.__dict__.setdefault("_pack_cache", {})
         hit = cache.get(kind)
         if hit is None or hit[0] != sig:

@@ -118,6 +118,22 @@ def posenc(x: torch.Tensor, n_freq: int, include_input: bool) -> torch.Tensor:
 
 
 # ---------------------------------------------------------------------------------------- K4
+# Packed weight images are cached per (parameter storage, version counter, PACK EPOCH).  The version counter follows ordinary
+# in-place updates (optimizer.step() of the default / foreach optimizers, load_state_dict, copy_ under no_grad) -- but NOT every
+# writer bumps it: torch's FUSED optimizers (Adam(fused=True)), writes through `p.data` and c10d collectives leave it untouched.
+# So every run_one_iter_of_nerf / run_one_iter_of_tinynerf call advances the pack epoch: the images are rebuilt once per
+# rendered frame or training step (a few 10-microsecond kernels), and a stale image can never outlive one call.
+_PACK_EPOCH = [0]
+
+
+def bump_pack_epoch() -> None:
+    _PACK_EPOCH[0] += 1
+
+
+def pack_epoch() -> int:
+    return _PACK_EPOCH[0]
+
+
 class PaperWeights:
     """Fragment-ordered weight image of one ConditionalBlendshapePaperNeRFModel on one device, re-packed
     whenever a parameter's version counter moves (i.e. after optimizer.step() / load_state_dict())."""
@@ -220,7 +236,7 @@ class PaperWeights:
         return self.packed_b
 
     def _signature(self):
-        return tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
+        return (_PACK_EPOCH[0],) + tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
 
     def get(self) -> torch.Tensor:
         sig = self._signature()

@@ -190,6 +190,7 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
     """T:165-290.  Same signature; returns (rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine,
     weights_fine[:, -1]), reshaped to image planes in `validation` mode (T:275-284)."""
     is_rad = torch.is_tensor(ray_directions_ablation)
+    ops.bump_pack_epoch()              # weight images are rebuilt once per call: see ops.PaperWeights (fused optimizers, .data writes)
     if options.dataset.no_ndc is False:
         raise NotImplementedError("NDC rays are not part of the NeRFace path (all configs use no_ndc: True)")
     restore_shapes = [ray_directions.shape, ray_directions.shape[:-1], ray_directions.shape[:-1]]

@@ -16,7 +16,7 @@ import torch
 
 from nerf import _hip as H
 from nerf import get_minibatches, get_ray_bundle, positional_encoding  # noqa: F401  (same imports as the reference script)
-from nerf.ops import _c
+from nerf.ops import _c, bump_pack_epoch, pack_epoch
 
 
 def _depths(ray_origins, near_thresh, far_thresh, num_samples, randomize):
@@ -70,7 +70,7 @@ class VeryTinyNerfModel(torch.nn.Module):
 
     def hip_packed(self):
         ps = [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        sig = (pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
         if self._packed is None or sig != self._sig:
             dev = H.require_device(*[p.detach() for p in ps])
             lib = H.lib()
@@ -84,7 +84,7 @@ class VeryTinyNerfModel(torch.nn.Module):
     def hip_packed_t(self):
         """Transposed fragment image of layer2 / layer3 for the backward chain (cached like hip_packed)."""
         ps = [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
-        sig = tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+        sig = (pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
         if getattr(self, "_packed_t", None) is None or sig != getattr(self, "_sig_t", None):
             dev = H.require_device(*[p.detach() for p in ps])
             lib = H.lib()
@@ -152,6 +152,7 @@ def run_one_iter_of_tinynerf(height, width, focal_length, tform_cam2world, near_
     compatibility -- encoding and chunking happen inside the fused kernel).  Returns rgb_predicted (H, W, 3)."""
     if not isinstance(model, VeryTinyNerfModel) or not model.fused_supported() or int(encoding_function_args) != 10:
         raise NotImplementedError("the fused tiny kernel is built for VeryTinyNerfModel(128, num_encoding_functions=10)")
+    bump_pack_epoch()                  # weight images are rebuilt once per call (fused optimizers do not bump version counters)
     ray_origins, ray_directions = get_ray_bundle(height, width, focal_length, tform_cam2world)
     depth_values = _depths(ray_origins, near_thresh, far_thresh, depth_samples_per_ray, True)       # default randomize=True
     dev = ray_origins.device

@@ -170,6 +170,7 @@ def cpu_baseline(n_rays=12288):
 TRAIN_BYTES_PER_POINT = {
     ("paper", "bf16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
     ("paper", "f32"): 4 * 2256 + (4 * (6 * 256 + 3 * 128) + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
+    ("paper", "f16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
     ("lcode", "f32"): 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
     ("lcode", "bf16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
 }
@@ -285,7 +286,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split-bf16 products, f32 accumulate)" if args.precision == "bf16x3" else "f32",
+            "dtype": {"bf16x3": "bf16x3 (split-bf16 products, f32 accumulate)", "f16x3": "f16x3 (split-fp16 products, f32 accumulate)"}.get(args.precision, "f32"),
             "data": "synthetic",
             "config": {"workload": f"configs[2]: {args.family}-model training iteration, 2048 rays from a 512x512 frame, 64+64 samples, "
                                    "noise 0.1, latent table 1000x32, Adam; one frame per rank, flat grad all-reduce",
@@ -534,7 +535,7 @@ def main():
     if not args.no_extras:
         train = {}
         keep_steps, keep_warm, keep_prec = args.steps, args.warmup, args.precision
-        for prec in ("f32", "bf16x3"):
+        for prec in ("f32", "f16x3", "bf16x3"):
             args.steps, args.warmup, args.precision = args.train_steps, 5, prec
             nerf.set_mlp_precision(prec)
             mc_t, mf_t = synth_params(0, dev, "paper"), synth_params(1, dev, "paper")

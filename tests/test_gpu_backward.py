@@ -244,6 +244,40 @@ def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
     assert e_lat < 1e-4 and e_ref < 1e-4                     # measured 7.6e-6 / 7.1e-6
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
+def test_fused_optimizer_updates_reach_the_kernels(hip_lib, gpu, precision):
+    """torch's FUSED optimizers update parameters without bumping their version counters, which the packed weight images were
+    once keyed on alone: the kernels kept evaluating the initial weights.  Every run_one_iter_of_nerf call now advances the pack
+    epoch, so the step after Adam(fused=True).step() sees the new weights: same rays, same random draws, different output --
+    and the same output as a model that was given the updated weights from scratch."""
+    import nerf
+    c = C.build_case("train_rand_64_64")
+    nerf.set_mlp_precision(precision)
+    mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+    table = torch.zeros((3, 32), device=gpu, requires_grad=True)
+    opt = torch.optim.Adam(list(mc.parameters()) + list(mf.parameters()) + [table], lr=1e-3, fused=True)
+    o = U.make_options(nerf, 64, 64, True, 0.1)
+    ex, ed = U.encoders(nerf)
+    rands, randns = U.case_random_lists(c)
+
+    def render(a, b, grad):
+        ctx = torch.enable_grad() if grad else torch.no_grad()
+        with ctx, U.injected_random(rands, randns):
+            return nerf.run_one_iter_of_nerf(512, 512, None, a, b, c["ro"].to(gpu), c["rd"].to(gpu), o, mode="train", encode_position_fn=ex,
+                                             encode_direction_fn=ed, expressions=c["expr"].to(gpu), background_prior=c["bg"].to(gpu),
+                                             latent_code=table[1])
+    out0 = render(mc, mf, True)
+    O.train_loss(out0[0], out0[3], c["tgt"].to(gpu), table[1]).backward()
+    versions = [p._version for p in mc.parameters()]
+    opt.step()
+    out1 = render(mc, mf, False)
+    assert float((out1[3] - out0[3].detach()).abs().max()) > 1e-5                     # the update is visible ...
+    mc2, mf2 = U.make_model(nerf, mc.state_dict(), gpu), U.make_model(nerf, mf.state_dict(), gpu)
+    out2 = render(mc2, mf2, False)
+    assert torch.equal(out1[3], out2[3]) and torch.equal(out1[0], out2[0])            # ... and it is exactly the updated model
+    print("fused Adam bumped version counters:", versions != [p._version for p in mc.parameters()])
+
+
 def test_adam_step_moves_live_parameters(hip_lib, gpu):
     """The trainer's loop (TR:389-392): backward, Adam over [coarse, fine, latent table], zero_grad; the cached weight
     image must follow the in-place update (version counters) and the gradient must land in the latent ROW."""
