@@ -379,6 +379,11 @@ def pmc_traffic(precision, timeout=240):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None, {"error": "rocprofv3 not found"}
+    # never nest profilers: a PMC pass started from a process that is itself being traced combines counter collection with
+    # tracing -- the combination this pool's nodes do not survive.  Under any rocprofiler the PMC passes are skipped.
+    under = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER"))]
+    if under or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None, {"skipped": "bench.py is running under a profiler (" + ", ".join(sorted(under)[:4]) + "); PMC passes not nested"}
     kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
     got = {}
     tmp = tempfile.mkdtemp(prefix="nf_pmc_")
