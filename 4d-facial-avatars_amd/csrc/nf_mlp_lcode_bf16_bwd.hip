@@ -9,7 +9,24 @@
 #include "nf_common.h"
 #include "nf_mlp_lcode_layout.h"
 
+// NFB_F16 = 1 (nf_mlp_lcode_f16_bwd.hip includes this file): the same chain on fp16 operand pairs, see nf_mlp_bf16_bwd.hip
+#ifndef NFB_F16
+#define NFB_F16 0
+#endif
+#if NFB_F16
+typedef _Float16 nfb_elt;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_f16
+#define NFB_BWD_NAME(x) x##_f16
+#ifndef NFB_TILE_GROUP
+#define NFB_TILE_GROUP 4
+#endif
+#else
+typedef __bf16 nfb_elt;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define NFB_MFMA __builtin_amdgcn_mfma_f32_32x32x16_bf16
+#define NFB_BWD_NAME(x) x##_bf16
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -60,11 +77,22 @@ static void nf_lcode_table_bf16_t(std::vector<uint32_t>& t) {
 
 static NfPackTable g_lcode_table_bt;
 
+#if NFB_F16
+extern "C" size_t nf_lcode_packed_bwd_f16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2 + NF_F16_TAIL_BYTES; }
+
+extern "C" int nf_lcode_pack_bwd_f16(const float* const* params, void* stream_out, nf_stream_t stream) {
+    NfLayerPairs<nfb::NL> lp;
+    for (int l = 0; l <= nfb::NL; ++l) lp.off[l] = nfb::pair_off(l);
+    return nf_pack_split_f16<nlc::NPARAMS, 17, nfb::NL>(g_lcode_table_bt, nf_lcode_table_bf16_t, params, stream_out, nfb::N_PAIRS * 512, lp,
+                                                        1.0f, stream);
+}
+#else
 extern "C" size_t nf_lcode_packed_bwd_bf16_bytes(void) { return (size_t)nfb::STREAM_BF16 * 2; }
 
 extern "C" int nf_lcode_pack_bwd_bf16(const float* const* params, void* stream_out, nf_stream_t stream) {
     return nf_pack_split_bf16<nlc::NPARAMS, 7>(g_lcode_table_bt, nf_lcode_table_bf16_t, params, stream_out, nfb::N_PAIRS * 512, stream);
 }
+#endif
 
 // =================================================================================================
 // B1 kernel
@@ -88,8 +116,8 @@ __device__ __forceinline__ void nfb_zero_tiles(f32x16 (&acc)[8]) {
 }
 
 __global__ void __launch_bounds__(256, 1)
-k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __restrict__ saved, const float* __restrict__ d_raw,
-                           int64_t n_points, float* __restrict__ dz) {
+NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const float* __restrict__ saved, const float* __restrict__ d_raw,
+                                    int64_t n_points, float* __restrict__ dz, const float* __restrict__ gscale) {
     using namespace nlc;
     __shared__ __attribute__((aligned(16))) char lds[NFB_LDS_BYTES];
     NfbCtx cx;
@@ -103,6 +131,20 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
     const int64_t p = p_raw < n_points ? p_raw : n_points - 1;
     const bool live = p_raw < n_points;
     const int64_t n = n_points;
+#if NFB_F16
+    const float* __restrict__ wscale = reinterpret_cast<const float*>(wstream + (size_t)nfb::STREAM_BF16 * 2);
+    float wsc[nfb::NL];
+#pragma unroll
+    for (int i = 0; i < nfb::NL; ++i) wsc[i] = wscale[nfb::NL + i];
+    float G = gscale[0], invG = gscale[1];
+#pragma unroll
+    for (int i = 0; i < nfb::NL; ++i) asm volatile("" : "+s"(wsc[i]));
+    asm volatile("" : "+s"(G), "+s"(invG));
+#define INV(L_) wsc[L_]
+#else
+    constexpr float G = 1.0f, invG = 1.0f;
+#define INV(L_) 1.0f
+#endif
 
     // ordinary loads first (d_raw, the five ReLU bit masks), then the ring
     const f32x4 d = reinterpret_cast<const f32x4*>(d_raw)[p];
@@ -117,15 +159,15 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
     bf16x8 bh[20], bl[20], th[20], tl[20];
     {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h == 0 && live) { x[0] = d.x; x[1] = d.y; x[2] = d.z; }
+        if (h == 0 && live) { x[0] = d.x * G; x[1] = d.y * G; x[2] = d.z * G; }
         nfb_split(x, th[0], tl[0]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { th[1][j] = (__bf16)0.f; tl[1][j] = (__bf16)0.f; }
+        for (int j = 0; j < 8; ++j) { th[1][j] = (nfb_elt)0.f; tl[1][j] = (nfb_elt)0.f; }
     }
     bf16x8 sh, sl;                                                     // d sigma k-step
     {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h == 0 && live) x[0] = d.w;
+        if (h == 0 && live) x[0] = d.w * G;
         nfb_split(x, sh, sl);
     }
     nfb_wait_vm<nfb::inflight_after(-1)>();
@@ -133,49 +175,53 @@ k_lcode_mlp_bwd_chain_bf16(const char* __restrict__ wstream, const float* __rest
     asm volatile("" ::: "memory");
 
     f32x16 acc[8];
-#define NFB_LC_BWD_FINISH(NO_, MASK_, ZSEC_)                                                             \
+#define NFB_LC_BWD_FINISH(L_, NO_, MASK_, ZSEC_)                                                         \
     do {                                                                                                 \
         if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                 \
+        if (NFB_F16) nfb_scale<NO_>(acc, INV(L_) * invG);          /* true gradients for dz */            \
         nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
-        nfb_to_operands<NO_, false>(acc, bh, bl, 0);                                                     \
+        nfb_to_operands<NO_, false>(acc, bh, bl, 0, G);                                                  \
     } while (0)
     // mask indices: layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
     nfb_zero_tiles<4>(acc);
     NFB_LAYER(0, acc, th, tl);
-    NFB_LC_BWD_FINISH(4, 4, Z_DIR);
+    NFB_LC_BWD_FINISH(0, 4, 4, Z_DIR);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(1, acc, bh, bl);
-    NFB_LC_BWD_FINISH(8, 3, Z_FEAT);
+    NFB_LC_BWD_FINISH(1, 8, 3, Z_FEAT);
     // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight (fc_alpha reads x), gated by layers_xyz.2's ReLU
 #pragma unroll
     for (int s = 0; s < 16; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
     th[16] = sh; tl[16] = sl;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { th[17][j] = (__bf16)0.f; tl[17][j] = (__bf16)0.f; }
+    for (int j = 0; j < 8; ++j) { th[17][j] = (nfb_elt)0.f; tl[17][j] = (nfb_elt)0.f; }
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(2, acc, th, tl);
-    NFB_LC_BWD_FINISH(8, 2, Z_X2);
+    NFB_LC_BWD_FINISH(2, 8, 2, Z_X2);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(3, acc, bh, bl);
-    NFB_LC_BWD_FINISH(8, 1, Z_X1);
+    NFB_LC_BWD_FINISH(3, 8, 1, Z_X1);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(4, acc, bh, bl);
-    NFB_LC_BWD_FINISH(8, 0, Z_X0);
+    NFB_LC_BWD_FINISH(4, 8, 0, Z_X0);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(5, acc, bh, bl);                                         // layer1 has no activation: dZ = d(out)
+    if (NFB_F16) nfb_scale<8>(acc, INV(5) * invG);
     nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L1 * n, 256, p_tile, n);
 #undef NFB_LC_BWD_FINISH
+#undef INV
 }
 
-int nfb_lcode_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                               nf_stream_t stream) {
+int NFB_BWD_NAME(nfb_lcode_launch_bwd_chain)(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                                             const float* gscale, nf_stream_t stream) {
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    hipLaunchKernelGGL(k_lcode_mlp_bwd_chain_bf16, dim3((unsigned)grid), dim3(256), 0, nf_s(stream),
-                       reinterpret_cast<const char*>(packed_t_bf16), saved, d_raw, n_points, dz);
+    hipLaunchKernelGGL(NFB_BWD_NAME(k_lcode_mlp_bwd_chain), dim3((unsigned)grid), dim3(256), 0, nf_s(stream),
+                       reinterpret_cast<const char*>(packed_t), saved, d_raw, n_points, dz, gscale);
     NF_RETURN_LAUNCH();
 }
 
+#if !NFB_F16
 // host-only: the gather table of this stream (one 32-bit code per bf16 element of the hi blocks: tensor id << 24 | element
 // offset, 0xFF000000 = zero) for tests/test_host.py; out == NULL returns the number of entries.  Transposed stream of the second model family.
 extern "C" long nf_lcode_stream_table_bwd_bf16(uint32_t* out, size_t n_entries) {
@@ -186,3 +232,4 @@ extern "C" long nf_lcode_stream_table_bwd_bf16(uint32_t* out, size_t n_entries) 
     for (size_t i = 0; i < t.size(); ++i) out[i] = t[i];
     return (long)t.size();
 }
+#endif

@@ -226,27 +226,33 @@ extern "C" size_t nf_lcode_grad_floats(void) { return (size_t)nlc::GRAD_FLOATS; 
 void nfb_dw_plan(int model, int64_t n_points, int64_t* pts_per_slice, int* n_slices);
 int nfb_launch_dw_gemm_bf16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
                             int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
-int nfb_lcode_launch_bwd_chain(const void* packed_t_bf16, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                               nf_stream_t stream);
+int nfb_launch_dw_gemm_f16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
+                           int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
+int nfb_lcode_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                                    const float* gscale, nf_stream_t stream);
+int nfb_lcode_launch_bwd_chain_f16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
+                                   const float* gscale, nf_stream_t stream);
 
 extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
     nf_bwd_plan(n_points, &pps, &ns);
     nfb_dw_plan(1, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
-    return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS;
+    return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS + 16;      // + gradient scale {G, 1/G, scratch}
 }
 
 static NfDwJobTable g_lcode_jobs;
 
 // grads: nf_lcode_grad_floats() floats = the 16 tensors in nerf.models.LCODE_KEYS order, flattened, then d latent (32)
-static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const float* cond, const float* saved,
-                             const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
-                             nf_stream_t stream) {
+// packed_t (exact f32) | packed_t_bf16 (split-bf16) | packed_t_f16 (split-fp16): exactly one non-NULL
+static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const void* packed_t_f16,
+                             const float* cond, const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
+                             size_t workspace_floats, float* grads, nf_stream_t stream) {
     using namespace nlc;
-    if (!packed || (!packed_t && !packed_t_bf16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 || n_samples <= 0)
+    if (!packed || (!packed_t && !packed_t_bf16 && !packed_t_f16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 ||
+        n_samples <= 0)
         return NF_EINVAL;
-    const bool split = packed_t_bf16 != nullptr;
+    const bool split = packed_t_bf16 != nullptr || packed_t_f16 != nullptr;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_lcode_bwd_workspace_floats(n_points)) return NF_EINVAL;
     const NfDwJob* jobs = nullptr;
@@ -258,6 +264,7 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
+    float* gscale = workspace + nf_lcode_bwd_workspace_floats(n_points) - 16;
     hipStream_t s = nf_s(stream);
     constexpr int NT = NF_MLP_NT;
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
@@ -265,8 +272,15 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
-    if (split) {
-        int rc = nfb_lcode_launch_bwd_chain(packed_t_bf16, saved, d_raw, n_points, dz, stream);
+    if (packed_t_f16) {
+        int rc = nf_grad_scale(d_raw, n_points * 4, gscale, stream);
+        if (rc) return rc;
+        rc = nfb_lcode_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
+        if (rc) return rc;
+        rc = nfb_launch_dw_gemm_f16(1, dz, d_raw, saved, n_points, pps, ns, slabs, gscale, stream);
+        if (rc) return rc;
+    } else if (split) {
+        int rc = nfb_lcode_launch_bwd_chain_bf16(packed_t_bf16, saved, d_raw, n_points, dz, nullptr, stream);
         if (rc) return rc;
         rc = nfb_launch_dw_gemm_bf16(1, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc) return rc;
@@ -287,7 +301,8 @@ extern "C" int nf_lcode_mlp_bwd(const float* packed, const float* packed_t, cons
                                 int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads,
                                 nf_stream_t stream) {
     if (!packed_t) return NF_EINVAL;
-    return nf_lcode_bwd_impl(packed, packed_t, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads, stream);
+    return nf_lcode_bwd_impl(packed, packed_t, nullptr, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads,
+                             stream);
 }
 
 // Same on the split-bf16 kernels (dX chain nf_mlp_lcode_bf16_bwd.hip, weight-gradient GEMMs nf_mlp_bf16_dw.hip); `saved` must come
@@ -296,8 +311,17 @@ extern "C" int nf_lcode_mlp_bwd_bf16(const float* packed, const void* packed_t_b
                                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
                                      float* grads, nf_stream_t stream) {
     if (!packed_t_bf16) return NF_EINVAL;
-    return nf_lcode_bwd_impl(packed, nullptr, packed_t_bf16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats, grads,
-                             stream);
+    return nf_lcode_bwd_impl(packed, nullptr, packed_t_bf16, nullptr, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats,
+                             grads, stream);
+}
+
+// Same on fp16 operand pairs ("f16x3"): `saved` from nf_lcode_mlp_fwd_train_f16, packed_t_f16 from nf_lcode_pack_bwd_f16.
+extern "C" int nf_lcode_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* cond, const float* saved,
+                                    const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                    float* grads, nf_stream_t stream) {
+    if (!packed_t_f16) return NF_EINVAL;
+    return nf_lcode_bwd_impl(packed, nullptr, nullptr, packed_t_f16, cond, saved, d_raw, n_rays, n_samples, workspace, workspace_floats,
+                             grads, stream);
 }
 
 // host-only self-test of this family's exact-f32 job table (tests/test_host.py)

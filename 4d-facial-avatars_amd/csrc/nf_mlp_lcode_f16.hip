@@ -32,6 +32,21 @@ extern "C" int nf_lcode_pack_f16(const float* const* params, void* stream_out, n
 #define NFB_KERNEL_NAME k_lcode_mlp_fwd_f16
 #include "nf_mlp_lcode_bf16_kernel.inc"
 
+// defined in nf_mlp_lcode_f16_train.hip (separate translation unit)
+int nfh_lcode_launch_train(const char* wstream, const float* cond, const float* ro, const float* rd, const float* rd_view, const float* z,
+                           int64_t n_points, int n_samples, float* raw, float* saved, unsigned grid, nf_stream_t stream);
+
+extern "C" int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                                          const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
+    if (!packed_f16 || !cond || !ro || !rd || !z || !raw || !saved || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
+    const int64_t n_points = n_rays * n_samples;
+    if (n_points == 0) return 0;
+    const int64_t grid = (n_points + 127) / 128;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    return nfh_lcode_launch_train(reinterpret_cast<const char*>(packed_f16), cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw,
+                                  saved, (unsigned)grid, stream);
+}
+
 extern "C" int nf_lcode_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                     const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
     if (!packed_f16 || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;

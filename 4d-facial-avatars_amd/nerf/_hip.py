@@ -67,6 +67,10 @@ _PROTOTYPES = {
     "nf_lcode_f16_flag_offset": (_Z, []),
     "nf_lcode_pack_f16": (C.c_int, [_P, _P, _P]),
     "nf_lcode_mlp_fwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_lcode_mlp_fwd_train_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
+    "nf_lcode_packed_bwd_f16_bytes": (_Z, []),
+    "nf_lcode_pack_bwd_f16": (C.c_int, [_P, _P, _P]),
+    "nf_lcode_mlp_bwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_lcode_mlp_fwd_train_bf16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_bf16_bytes": (_Z, []),
     "nf_lcode_pack_bwd_bf16": (C.c_int, [_P, _P, _P]),

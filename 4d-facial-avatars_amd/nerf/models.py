@@ -191,6 +191,7 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         "bf16": ("nf_lcode_packed_bf16_bytes", "nf_lcode_pack_bf16", torch.uint8),
         "bf16_t": ("nf_lcode_packed_bwd_bf16_bytes", "nf_lcode_pack_bwd_bf16", torch.uint8),
         "f16": ("nf_lcode_packed_f16_bytes", "nf_lcode_pack_f16", torch.uint8),
+        "f16_t": ("nf_lcode_packed_bwd_f16_bytes", "nf_lcode_pack_bwd_f16", torch.uint8),
     }
 
     def _hip_pack(self, kind):
@@ -286,9 +287,27 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                     H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
                                                  n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
                 return raw, None
-            split = ops.get_mlp_precision() == "bf16x3"
+            prec = ops.get_mlp_precision()
+            split = "f16" if prec == "f16x3" else prec == "bf16x3"
             saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)
-            if split:
+            if split == "f16" and not getattr(self, "_in_f16_probe", False):
+                # range probe (weights move every step): the first training call and every 128th
+                n_calls = self.__dict__["_f16_train_calls"] = self.__dict__.get("_f16_train_calls", 0) + 1
+                if n_calls % 128 == 1:
+                    self._in_f16_probe = True
+                    try:
+                        amax = self._f16_preflight(ro, rd, z, rd_view, expr, latent, near, far)
+                    finally:
+                        self._in_f16_probe = False
+                    if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
+                        raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g}, '
+                                           f'within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit ({ops.F16_ACT_LIMIT:g}) -- train '
+                                           f'this model with "f32" or "bf16x3"')
+            if split == "f16":
+                H.check(lib.nf_lcode_mlp_fwd_train_f16(H.ptr(self._hip_pack("f16")), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
+                                                       H.ptr(z), n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
+                        "nf_lcode_mlp_fwd_train_f16")
+            elif split:
                 H.check(lib.nf_lcode_mlp_fwd_train_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
                                                         H.ptr(z), n_rays, n_samples, H.ptr(raw), H.ptr(saved), H.stream_ptr(dev)),
                         "nf_lcode_mlp_fwd_train_bf16")
@@ -309,7 +328,11 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         flat = torch.empty(lib.nf_lcode_grad_floats(), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            if split:     # forward was the split-bf16 training forward (bit masks present): split-bf16 chain + dW GEMMs
+            if split == "f16":     # forward was the split-fp16 training forward: split-fp16 chain + dW GEMMs
+                H.check(lib.nf_lcode_mlp_bwd_f16(H.ptr(packed), H.ptr(self._hip_pack("f16_t")), H.ptr(cond), H.ptr(saved), H.ptr(d_raw),
+                                                 n_rays, n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)),
+                        "nf_lcode_mlp_bwd_f16")
+            elif split:     # forward was the split-bf16 training forward (bit masks present): split-bf16 chain + dW GEMMs
                 H.check(lib.nf_lcode_mlp_bwd_bf16(H.ptr(packed), H.ptr(self._hip_packed_bf16_t()), H.ptr(cond), H.ptr(saved), H.ptr(d_raw),
                                                   n_rays, n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)),
                         "nf_lcode_mlp_bwd_bf16")

@@ -173,6 +173,7 @@ TRAIN_BYTES_PER_POINT = {
     ("paper", "f16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
     ("lcode", "f32"): 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
     ("lcode", "bf16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+    ("lcode", "f16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
 }
 
 

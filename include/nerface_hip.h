@@ -175,6 +175,13 @@ size_t nf_lcode_f16_flag_offset(void);
 int nf_lcode_pack_f16(const float* const* params, void* stream_out, nf_stream_t stream);
 int nf_lcode_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+/* training the second family on the split-fp16 kernels (as nf_paper_mlp_fwd_train_f16 / nf_paper_mlp_bwd_f16) */
+int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                               const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
+size_t nf_lcode_packed_bwd_f16_bytes(void);
+int nf_lcode_pack_bwd_f16(const float* const* params, void* stream_out, nf_stream_t stream);
+int nf_lcode_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* cond, const float* saved, const float* d_raw,
+                         int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats, float* grads, nf_stream_t stream);
 
 /* Training of the same family, exact f32 (autograd through M:590-636 as the trainer drives it, TR:355-392):
  * forward that also fills `saved` (nf_lcode_saved_floats(n_rays*n_samples) floats), transposed weight image, and the
