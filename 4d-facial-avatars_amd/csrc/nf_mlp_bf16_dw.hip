@@ -221,6 +221,30 @@ __device__ __forceinline__ void nfb_dw_split(const float (&x)[8], bf16x8& hi, bf
     }
 }
 
+#if NFB_F16
+// (hi, lo) fp16 split of x * s (s a power of two) on the mixed-precision FMA instructions: v_fma_mixlo/hi_f16 multiply and
+// round to fp16 in one step, v_fma_mix_f32 forms the exact residual x * s - hi straight from the packed halves, one packed
+// convert rounds it -- 2.5 instructions per element instead of 5 (multiply, convert, convert back, subtract, convert); the
+// result is bit-identical (tools/micro probe), and this kernel sits on the edge of being conversion-bound.
+__device__ __forceinline__ void nfb_dw_split_scaled(const float (&x)[8], float s, bf16x8& hi, bf16x8& lo) {
+    unsigned hw[4], lw[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned h;
+        float r0, r1;
+        asm("v_fma_mixlo_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "=v"(h) : "v"(x[2 * q]), "v"(s));
+        asm("v_fma_mixhi_f16 %0, %1, %2, 0 op_sel_hi:[0,0,0]" : "+v"(h) : "v"(x[2 * q + 1]), "v"(s));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(r0) : "v"(x[2 * q]), "v"(s), "v"(h));
+        asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r1) : "v"(x[2 * q + 1]), "v"(s), "v"(h));
+        asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(lw[q]) : "v"(r0), "v"(r1));
+        hw[q] = h;
+    }
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    hi = __builtin_bit_cast(bf16x8, (u32x4_t){hw[0], hw[1], hw[2], hw[3]});
+    lo = __builtin_bit_cast(bf16x8, (u32x4_t){lw[0], lw[1], lw[2], lw[3]});
+}
+#endif
+
 // L step for one tile: lane (h, c) <- feature c of points p0 + 8 h .. + 7 (zero beyond the slice / the section width)
 // L step: raw buffer loads.  voff = this lane's byte offset of (point 8 h of the stage, its feature) within the slice's rows
 // of the section, or 0x80000000 for lanes past the section width; the 8 points are reached through the scalar offset
@@ -300,10 +324,7 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
         {
             bf16x8 hi, lo;
 #if NFB_F16
-            float xsc[8];
-#pragma unroll
-            for (int j = 0; j < 8; ++j) xsc[j] = xc[j] * t_scale;
-            nfb_dw_split(xsc, hi, lo);
+            nfb_dw_split_scaled(xc, t_scale, hi, lo);
 #else
             nfb_dw_split(xc, hi, lo);
 #endif
@@ -351,10 +372,7 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
         nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
         bf16x8 hi, lo;
 #if NFB_F16
-        float xsc[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xsc[j] = xt[j] * t_scale;
-        nfb_dw_split(xsc, hi, lo);
+        nfb_dw_split_scaled(xt, t_scale, hi, lo);
 #else
         nfb_dw_split(xt, hi, lo);
 #endif
