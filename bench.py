@@ -443,13 +443,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the product has no CPU path)")
+    backend = os.environ.get("NERFACE_DIST_BACKEND", "nccl")           # "gloo": several ranks on one GPU (tests of the N > 1 path)
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)        # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group(backend=backend)
 
     import __graft_entry__ as G
     if rank == 0:

@@ -103,6 +103,29 @@ def test_two_ranks_one_gpu_gloo_train_and_eval(hip_lib, gpu, tmp_path):
     assert sorted(os.listdir(out2)) == [f"{i:04d}.png" for i in range(5)]
 
 
+def test_bench_two_ranks_one_gpu_gloo(hip_lib, gpu):
+    """bench.py's N > 1 path as the driver launches it (torch.distributed.run, one JSON line from rank 0): two ranks on this one
+    GPU with NERFACE_DIST_BACKEND=gloo.  Frames are sharded (weak scaling: rays_total doubles), the extras run under the same
+    protocol, and the data-parallel `train` object goes through the flat gradient all-reduce."""
+    import json
+    import subprocess
+    env = dict(os.environ, NERFACE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29700 + (os.getpid() % 1000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--train-steps", "3"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["value"] > 0
+    assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512 * 512) < 1.0                    # two ranks x one frame each
+    assert "split_f16" in d and "split_bf16" in d and "cpu_baseline" not in d
+    assert set(k for k in d["train"] if k != "workload") == {"f32", "f16x3", "bf16x3"}
+    assert "data parallel over 2 GPUs" in d["train"]["workload"]
+    assert d["roofline"]["traffic"] is None                                                     # PMC passes are an N = 1 extra
+
+
 def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
     """The same two launchers with `type: ConditionalBlendshapeLearnableCodeNeRFModel` in the config (as 6 shipped configs
     have): trains (exact-f32 kernels), checkpoints with this family's state_dict keys, renders in both precisions."""
