@@ -206,3 +206,33 @@ def test_model_forward_and_run_network_on_encoded_inputs(hip_lib, gpu):
     assert torch.all((rf.reshape(-1, 4).double() - ref).abs().amax(dim=0) <= 3e-5 * scale + 3e-5)
     with pytest.raises(NotImplementedError):
         m(x87.to(gpu), c["expr"].to(gpu), c["latent"].to(gpu).requires_grad_(True))
+
+
+def test_empty_inputs(hip_lib, gpu):
+    """Zero rays through every stage: shapes come back empty, nothing is launched, nothing raises."""
+    import nerf
+    from nerf import ops
+    c = C.build_case("eval_det_64_128")
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False)
+    m.load_state_dict(c["p_fine"])
+    m.to(gpu)
+    e = lambda *shape: torch.empty(shape, device=gpu)
+    z = ops.sample_coarse(0, 64, O.NEAR, O.FAR, gpu, None)
+    assert z.shape == (0, 64)
+    hw = m.hip_weights()
+    cond = ops.paper_condition(hw.get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    for raw in (ops.paper_mlp_fwd(hw.get(), cond, e(0, 3), e(0, 3), z), ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, e(0, 3), e(0, 3), z),
+                ops.paper_mlp_fwd_f16(hw.get_f16(), cond, e(0, 3), e(0, 3), z)):
+        assert raw.shape == (0, 64, 4)
+    rgb, disp, acc, w = ops.volume_render_fwd(raw, z, e(0, 3), None, e(0, 3))
+    assert rgb.shape == (0, 3) and w.shape == (0, 64)
+    assert ops.resample_merge(z, w, 128, None).shape == (0, 192)
+    assert ops.sample_pdf(e(0, 63), e(0, 62), 128, None).shape == (0, 128)
+    assert ops.sort_rows(e(0, 17)).shape == (0, 17)
+    opt = __import__("tests.util", fromlist=["x"]).make_options(nerf, 64, 128, False, 0.0)
+    ex, ed = __import__("tests.util", fromlist=["x"]).encoders(nerf)
+    with torch.no_grad():
+        out = nerf.run_one_iter_of_nerf(512, 512, None, m, m, e(0, 3), e(0, 3), opt, mode="train", encode_position_fn=ex, encode_direction_fn=ed,
+                                        expressions=c["expr"].to(gpu), background_prior=e(0, 3), latent_code=c["latent"].to(gpu))
+    assert [tuple(t.shape) for t in out] == [(0, 3), (0,), (0,), (0, 3), (0,), (0,), (0,)]
