@@ -185,6 +185,7 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
 
 static int nf_lcode_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
+    if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
     if (!packed || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;

@@ -61,6 +61,7 @@ extern "C" int nf_lcode_pack_bf16(const float* const* params, void* stream_out, 
 // cond must be the padded table nf_lcode_condition fills (nf_lcode_cond_floats() floats >= 10 KiB)
 extern "C" int nf_lcode_mlp_fwd_bf16(const void* packed_bf16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                      const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
     if (!packed_bf16 || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;

@@ -38,6 +38,7 @@ int nfh_lcode_launch_train(const char* wstream, const float* cond, const float* 
 
 extern "C" int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                           const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
+    if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
     if (!packed_f16 || !cond || !ro || !rd || !z || !raw || !saved || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;
@@ -49,6 +50,7 @@ extern "C" int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* c
 
 extern "C" int nf_lcode_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                     const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream) {
+    if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
     if (!packed_f16 || !cond || !ro || !rd || !z || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;

@@ -68,8 +68,8 @@ __global__ void __launch_bounds__(256) k_sample_coarse(int64_t n_rays, int nc, f
 
 extern "C" int nf_sample_coarse(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
                                 const float* t_rand, float* z, nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (n_rays < 0 || n_coarse <= 0 || !z || !t_vals) return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t total = n_rays * n_coarse;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_sample_coarse, dim3(grid), dim3(256), 0, nf_s(stream), n_rays, n_coarse, near_z, far_z, t_vals,

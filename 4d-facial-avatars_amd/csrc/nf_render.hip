@@ -122,8 +122,8 @@ __global__ void __launch_bounds__(256) k_volume_render_fwd(const float* __restri
 extern "C" int nf_volume_render_fwd(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
                                     int64_t n_rays, int n_samples, int white_background, float* rgb, float* disp,
                                     float* acc, float* weights, nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!raw || !z || !rd || !rgb || !disp || !acc || !weights || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_volume_render_fwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, z, rd, noise, bg, n_rays,
@@ -135,8 +135,8 @@ extern "C" int nf_volume_render_fwd(const float* raw, const float* z, const floa
 // |rd|; returns (rgb_map, depth_map, acc_map).  depth: (n_rays, n_samples).
 extern "C" int nf_render_volume_density(const float* raw, const float* depth, int64_t n_rays, int n_samples, float* rgb,
                                         float* depth_map, float* acc, nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!raw || !depth || !rgb || !depth_map || !acc || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_volume_render_fwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), raw, depth, (const float*)nullptr,
@@ -220,8 +220,8 @@ __global__ void __launch_bounds__(256) k_volume_render_bwd(const float* __restri
 static int nf_volume_render_bwd_impl(const float* raw, const float* z, const float* rd, const float* noise, const float* bg,
                                      const float* d_rgb, int64_t n_rays, int n_samples, int white_background, float* d_raw,
                                      int mode, nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!raw || !z || (!rd && (mode & 1)) || !d_rgb || !d_raw || n_rays < 0 || n_samples <= 0 || n_samples > 64 * NF_MAX_CHUNKS) return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     const int nch = (n_samples + 63) / 64;
@@ -341,8 +341,8 @@ __global__ void __launch_bounds__(256) k_sample_pdf(const float* __restrict__ bi
 
 extern "C" int nf_sample_pdf_ex(const float* bins, const float* weights, const float* u, int64_t u_row_stride, int64_t n_rays,
                                 int n_bins, int n_out, float* samples, int* inds, float* cdf, nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!bins || !weights || !u || !samples || n_rays < 0 || n_bins < 2 || n_bins > NF_MAX_BINS || n_out <= 0) return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_sample_pdf, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), bins, weights, u, u_row_stride, n_rays,
@@ -391,8 +391,8 @@ __global__ void __launch_bounds__(256) k_sort_rows(const float* __restrict__ in,
 }
 
 extern "C" int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream) {
+    if (n_rows == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!in || !out || n_rows < 0 || n_cols <= 0 || n_cols > NF_MAX_SORT) return NF_EINVAL;
-    if (n_rows == 0) return 0;
     const int64_t grid = (n_rows + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_sort_rows, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), in, n_rows, n_cols, out);
@@ -440,10 +440,10 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
                                  int64_t n_rays, int n_coarse, int n_fine, float* z_samples, float* z_fine,
                                  nf_stream_t stream) {
+    if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (!z_coarse || !w_coarse || !u || !z_fine || n_rays < 0 || n_coarse < 3 || n_coarse - 1 > NF_MAX_BINS || n_fine <= 0 ||
         n_coarse + n_fine > NF_MAX_SORT)
         return NF_EINVAL;
-    if (n_rays == 0) return 0;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(k_resample_merge, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), z_coarse, w_coarse, u, u_row_stride,

@@ -105,6 +105,7 @@ k_tiny_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ ro, c
 // depth: (n_rays, n_samples) when depth_per_ray != 0, else one (n_samples) table shared by all rays.
 static int nf_tiny_fwd_impl(const float* packed, const float* ro, const float* rd, const float* depth, int depth_per_ray, int64_t n_rays,
                             int n_samples, float* raw, float* saved, nf_stream_t stream) {
+    if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
     if (!packed || !ro || !rd || !depth || !raw || n_rays < 0 || n_samples <= 0) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (n_points == 0) return 0;
