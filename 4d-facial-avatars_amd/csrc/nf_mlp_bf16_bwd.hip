@@ -10,8 +10,8 @@
 #include "nf_mlp_layout.h"
 
 // NFB_F16 = 1 (nf_mlp_f16_bwd.hip includes this file): the same chain on fp16 operand pairs -- transposed weight stream with
-// per-layer power-of-two scales (nf_pack.h), gradients carried times a per-launch power of two G chosen from max |d_raw|
-// (gscale = {G, 1 / G} on the device, nf_grad_scale in nf_pack.h) so that they sit in the middle of fp16's exponent range.
+// per-layer power-of-two scales (nf_pack.h), gradients carried times a per-POINT power of two chosen layer by layer from the
+// point's largest gradient (block floating point, nf_mlp_bf16_machinery.inc) so that they sit at the top of fp16's exponent range.
 #ifndef NFB_F16
 #define NFB_F16 0
 #endif
@@ -125,7 +125,7 @@ __device__ __forceinline__ void nfb_zero_tiles(f32x16 (&acc)[8]) {
 
 __global__ void __launch_bounds__(256, 1)
 NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const float* __restrict__ saved, const float* __restrict__ d_raw,
-                                    int64_t n_points, float* __restrict__ dz, const float* __restrict__ gscale) {
+                                    int64_t n_points, float* __restrict__ dz, float* __restrict__ gscale) {
     using namespace nfl;
     __shared__ __attribute__((aligned(16))) char lds[NFB_LDS_BYTES];
     NfbCtx cx;
@@ -139,20 +139,25 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     const int64_t p = p_raw < n_points ? p_raw : n_points - 1;
     const bool live = p_raw < n_points;
     const int64_t n = n_points;
+    // The 16-bit-input MFMA accumulates with a small rounding bias toward -inf (about -2^-26 of the addends, measured: profiles/
+    // r02_experiments.md section 8) that survives in sums over points where the gradients themselves cancel (bias gradients:
+    // sum |dz| / |sum dz| = 300 ... 12000).  Every point therefore runs the chain with its own sign: odd points carry -gradient
+    // in the operands (the sign is taken back when dz is written), so the bias alternates over points and cancels like noise.
+    const float sgn = (c & 1) ? -1.0f : 1.0f;
 #if NFB_F16
-    // operands carry gradient * G; INV(l) = 1 / s_W(l) turns an accumulator into the next operand (still times G) and
-    // INV(l) / G into the true pre-activation gradient that is written to `dz`.  All scalars fetched once, up front.
+    // operands carry gradient * g, g the point's own (signed) power-of-two scale (block floating point, machinery.inc);
+    // INV(l) = 1 / s_W(l), so INV(l) / g turns an accumulator into the true pre-activation gradient that is written to `dz`.
     const float* __restrict__ wscale = reinterpret_cast<const float*>(wstream + (size_t)nfb::STREAM_BF16 * 2);
     float wsc[nfb::NL];
 #pragma unroll
     for (int i = 0; i < nfb::NL; ++i) wsc[i] = wscale[nfb::NL + i];
-    float G = gscale[0], invG = gscale[1];
 #pragma unroll
     for (int i = 0; i < nfb::NL; ++i) asm volatile("" : "+s"(wsc[i]));
-    asm volatile("" : "+s"(G), "+s"(invG));
+    unsigned* lmax = reinterpret_cast<unsigned*>(gscale);
+    const unsigned seen = cx.lane < 16 ? __atomic_load_n(lmax + cx.lane, __ATOMIC_RELAXED) : 0u;   // possibly stale: only saves atomics
 #define INV(L_) wsc[L_]
 #else
-    constexpr float G = 1.0f, invG = 1.0f;
+    const float G = sgn, invG = sgn;
 #define INV(L_) 1.0f
 #endif
 
@@ -167,6 +172,15 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
 
     bf16x8 bh[20], bl[20], th[20], tl[20];
+#if NFB_F16
+    float invG;
+    float lm[NFB_GS_DRAW + 1];                                          // this lane's max |gradient| per section (slots: machinery.inc)
+#pragma unroll
+    for (int i = 0; i <= NFB_GS_DRAW; ++i) lm[i] = 0.0f;
+    lm[NFB_GS_DRAW] = live ? fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))) : 0.0f;
+    float G = sgn * nfb_pow2_scale(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), invG);  // the rgb gradient of this point
+    invG *= sgn;
+#endif
     {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (h == 0 && live) { x[0] = d.x * G; x[1] = d.y * G; x[2] = d.z * G; }
@@ -174,70 +188,85 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) { th[1][j] = (nfb_elt)0.f; tl[1][j] = (nfb_elt)0.f; }
     }
-    bf16x8 sh, sl;                                                     // d sigma k-step
-    {
-        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h == 0 && live) x[0] = d.w * G;
-        nfb_split(x, sh, sl);
-    }
     nfb_wait_vm<nfb::inflight_after(-1)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     f32x16 acc[8];
-#define NFB_BWD_FINISH(L_, NO_, MASK_, ZSEC_)                                                            \
+    // EXTRA_: a gradient that joins the next layer's operands (d sigma), so that the point's scale covers it
+#if NFB_F16
+#define NFB_BWD_RESCALE(L_, NO_, EXTRA_)                                                                 \
+    do {                                                                                                 \
+        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc) : 0.0f);                                  \
+        G = sgn * nfb_pow2_scale(fmaxf(lm[L_], EXTRA_), invG);                                           \
+        invG *= sgn;                                                                                     \
+    } while (0)
+#else
+#define NFB_BWD_RESCALE(L_, NO_, EXTRA_) (void)0
+#endif
+#define NFB_BWD_FINISH(L_, NO_, MASK_, ZSEC_, EXTRA_)                                                    \
     do {                                                                                                 \
         if ((MASK_) >= 0) nfb_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                    \
-        if (NFB_F16) nfb_scale<NO_>(acc, INV(L_) * invG);          /* true gradients for dz */            \
+        nfb_scale<NO_>(acc, INV(L_) * invG);                       /* true gradients for dz */            \
         nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
+        NFB_BWD_RESCALE(L_, NO_, EXTRA_);                                                                \
         nfb_to_operands<NO_, false>(acc, bh, bl, 0, G);                                                  \
     } while (0)
     // mask indices: h0..h5 -> 0..5, layers_dir.0..2 outputs -> 6..8
     nfb_zero_tiles<4>(acc);
     NFB_LAYER(0, acc, th, tl);
-    NFB_BWD_FINISH(0, 4, 8, Z_D2);
+    NFB_BWD_FINISH(0, 4, 8, Z_D2, 0.0f);
     nfb_zero_tiles<4>(acc);
     NFB_LAYER(1, acc, bh, bl);
-    NFB_BWD_FINISH(1, 4, 7, Z_D1);
+    NFB_BWD_FINISH(1, 4, 7, Z_D1, 0.0f);
     nfb_zero_tiles<4>(acc);
     NFB_LAYER(2, acc, bh, bl);
-    NFB_BWD_FINISH(2, 4, 6, Z_D0);
+    NFB_BWD_FINISH(2, 4, 6, Z_D0, fabsf(d.w));
     // d feat = dZ_D0 . layers_dir.0[:, :256] + d sigma * fc_alpha.weight (no activation on feat)
 #pragma unroll
     for (int s = 0; s < 8; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
-    th[8] = sh; tl[8] = sl;
+    {                                                                  // d sigma k-step, at the scale of dZ_D0's operands
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && live) x[0] = d.w * G;
+        nfb_split(x, th[8], tl[8]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { th[9][j] = (nfb_elt)0.f; tl[9][j] = (nfb_elt)0.f; }
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(3, acc, th, tl);
-    NFB_BWD_FINISH(3, 8, -1, Z_FEAT);
+    NFB_BWD_FINISH(3, 8, -1, Z_FEAT, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(4, acc, bh, bl);
-    NFB_BWD_FINISH(4, 8, 5, Z_L5);
+    NFB_BWD_FINISH(4, 8, 5, Z_L5, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(5, acc, bh, bl);
-    NFB_BWD_FINISH(5, 8, 4, Z_L4);
+    NFB_BWD_FINISH(5, 8, 4, Z_L4, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(6, acc, bh, bl);
-    NFB_BWD_FINISH(6, 8, 3, Z_L3);
+    NFB_BWD_FINISH(6, 8, 3, Z_L3, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(7, acc, bh, bl);
-    NFB_BWD_FINISH(7, 8, 2, Z_L2);
+    NFB_BWD_FINISH(7, 8, 2, Z_L2, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(8, acc, bh, bl);
-    NFB_BWD_FINISH(8, 8, 1, Z_L1);
+    NFB_BWD_FINISH(8, 8, 1, Z_L1, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(9, acc, bh, bl);
     nfb_apply_mask<8>(acc, mask[0]);
-    if (NFB_F16) nfb_scale<8>(acc, INV(9) * invG);
+    nfb_scale<8>(acc, INV(9) * invG);
     nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L0 * n, 256, p_tile, n);
+    NFB_BWD_RESCALE(9, 8, 0.0f);                                       // only for max |dZ_L0| (the weight-gradient kernel's scale)
+#if NFB_F16
+    nfb_flush_layer_max<NFB_GS_DRAW + 1>(lm, lmax, seen, cx.lane);
+#endif
 #undef NFB_BWD_FINISH
+#undef NFB_BWD_RESCALE
 #undef INV
 }
 
-// gscale: device {G, 1 / G} (fp16 instantiation; ignored by the bf16 one)
+// gscale: 16 zeroed words on the device that receive max |dz| per layer (fp16 instantiation; ignored by the bf16 one)
 int NFB_BWD_NAME(nfb_launch_bwd_chain)(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                                       const float* gscale, nf_stream_t stream) {
+                                       float* gscale, nf_stream_t stream) {
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(NFB_BWD_NAME(k_paper_mlp_bwd_chain), dim3((unsigned)grid), dim3(256), 0, nf_s(stream),

@@ -23,7 +23,8 @@
 #include <vector>
 
 // NFB_F16 = 1 (nf_mlp_f16_dw.hip includes this file): the same kernel on fp16 operand pairs.  Saved activations are converted
-// times 2^4 and gradients times the per-launch power of two G of the backward chain (gscale = {G, 1 / G}, nf_pack.h), so that
+// times 2^4 and every gradient section times its own power of two, from max |dz| of the section that the backward chain leaves in
+// `gscale` (float bits; slot = NfbDwSeg::gs), so that
 // both sit inside fp16's exponent range; the accumulators are multiplied by 1 / (16 G) before they go to the slab.
 #include "nf_mlp_bf16_common.h"
 #include "nf_mlp_lcode_layout.h"
@@ -37,6 +38,7 @@ struct NfbDwSeg {
     int kind;      // 0: dz section, 1: d_raw, 2: saved section
     int sec;       // section offset (floats per point)
     int width;     // floats per point
+    int gs;        // kinds 0, 1: slot of the section's max |gradient| in the chain's table (fp16 instantiation)
 };
 struct NfbDwTile {   // one 32-feature operand tile of a stage
     int seg, f0;     // segment, first feature
@@ -67,19 +69,20 @@ static __constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
 // job-table builder helpers (host)
 struct NfbDwBuilder {
     NfbDwJob* jobs;
+    int (*slot_of)(int zsec);          // dz section -> the chain's layer index (slot of max |dz|)
     int nj = 0;
     int first_tile[4];
     NfbDwJob& new_job() {
         NfbDwJob& j = jobs[nj++];
         j.nseg = j.ntile = 0;
-        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0};
+        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0, -1};
         for (auto& t : j.tile) t = NfbDwTile{0, 0, -1};
         for (auto& p : j.prod) p = NfbDwProd{0, 0, 0, 0, 0, 0, 0, 0};   // idle wave: multiplies tiles 0, 1 and stores nothing
         return j;
     }
     // segment + its tiles; cs >= 0: slab offset of the column sums of the section
     int add_seg(NfbDwJob& j, int kind, int sec, int width, int cs) {
-        j.seg[j.nseg] = NfbDwSeg{kind, sec, width};
+        j.seg[j.nseg] = NfbDwSeg{kind, sec, width, kind == 2 ? -1 : (kind == 1 ? 10 : slot_of(sec))};
         first_tile[j.nseg] = j.ntile;
         for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
         return j.nseg++;
@@ -109,7 +112,7 @@ struct NfbDwBuilder {
 // second model family (layouts: nf_mlp_lcode_layout.h)
 static void nfb_build_dw_jobs_lcode(NfbDwJob* jobs) {
     using namespace nlc;
-    NfbDwBuilder b{jobs};
+    NfbDwBuilder b{jobs, [](int z) { return z == Z_DIR ? 0 : z == Z_FEAT ? 1 : z == Z_X2 ? 2 : z == Z_X1 ? 3 : z == Z_X0 ? 4 : 5; }};
     b.layer256(Z_X0, S_L1, G_X0, CS_L1 + 256);
     b.layer256(Z_X1, S_X0, G_X1, CS_L1 + 512);
     b.layer256(Z_X2, S_X1, G_X2, CS_L1 + 768);
@@ -142,17 +145,24 @@ static void nfb_build_dw_jobs(NfbDwJob* jobs) {
     using namespace nfl;
     int nj = 0;
     int first_tile[4];
+    // dz section -> the chain's layer index (slot of max |dz|)
+    auto slot_of = [](int z) {
+        const int order[10] = {Z_D2, Z_D1, Z_D0, Z_FEAT, Z_L5, Z_L4, Z_L3, Z_L2, Z_L1, Z_L0};
+        for (int i = 0; i < 10; ++i)
+            if (order[i] == z) return i;
+        return -1;
+    };
     auto new_job = [&]() -> NfbDwJob& {
         NfbDwJob& j = jobs[nj++];
         j.nseg = j.ntile = 0;
-        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0};
+        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0, -1};
         for (auto& t : j.tile) t = NfbDwTile{0, 0, -1};
         for (auto& p : j.prod) p = NfbDwProd{0, 0, 0, 0, 0, 0, 0, 0};   // idle wave: multiplies tiles 0, 1 and stores nothing
         return j;
     };
     // segment + its tiles; cs >= 0: slab offset of the column sums of the section
     auto add_seg = [&](NfbDwJob& j, int kind, int sec, int width, int cs) {
-        j.seg[j.nseg] = NfbDwSeg{kind, sec, width};
+        j.seg[j.nseg] = NfbDwSeg{kind, sec, width, kind == 2 ? -1 : (kind == 1 ? 10 : slot_of(sec))};
         first_tile[j.nseg] = j.ntile;
         for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
         return j.nseg++;
@@ -222,6 +232,13 @@ __device__ __forceinline__ void nfb_dw_split(const float (&x)[8], bf16x8& hi, bf
 }
 
 #if NFB_F16
+// 2^(13 - k) for a section whose largest |gradient| (float bits) lies in [2^k, 2^(k+1)); exponents clamp to [-60, 60]
+__device__ __forceinline__ float nfb_dw_pow2_scale(unsigned max_bits, float& inv) {
+    int se = 267 - (int)(max_bits >> 23);
+    se = se < 67 ? 67 : (se > 187 ? 187 : se);
+    inv = __uint_as_float((unsigned)(254 - se) << 23);
+    return __uint_as_float((unsigned)se << 23);
+}
 // (hi, lo) fp16 split of x * s (s a power of two) on the mixed-precision FMA instructions: v_fma_mixlo/hi_f16 multiply and
 // round to fp16 in one step, v_fma_mix_f32 forms the exact residual x * s - hi straight from the packed halves, one packed
 // convert rounds it -- 2.5 instructions per element instead of 5 (multiply, convert, convert back, subtract, convert); the
@@ -292,9 +309,20 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
     const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(t_g), (short)0, (int)(n_stages * NFB_DW_PTS * t_stride_b), 0x00020000);
     const unsigned t_voff = (t_on && t_fok) ? 4u * (unsigned)(tl.f0 + c) + (unsigned)(8 * h) * t_stride_b : 0x80000000u;
+    // Odd slices accumulate MINUS their gradient (the gradient operand is negated on the way into the MFMA, the slab entry on the
+    // way out): the 16-bit-input MFMA accumulation is biased toward -inf by a fraction of an ulp per step, 700+ steps deep here,
+    // and alternating the sign over slices lets that bias cancel in the slab reduction instead of adding up.
+    const float slice_sgn = (slice & 1) ? -1.0f : 1.0f;
+#if !NFB_F16
+    const unsigned t_flip = (tsg.kind != 2 && (slice & 1)) ? 0x80000000u : 0u;     // sign bit of the raw floats (after their column sum)
+#endif
 #if NFB_F16
-    const float t_scale = tsg.kind == 2 ? 16.0f : gscale[0];          // activations x 2^4, gradients x G (exact powers of two)
-    const float out_scale = gscale[1] * (1.0f / 16.0f);
+    // activations x 2^4, gradient sections x the power of two that lifts their largest entry into [2^13, 2^14)
+    const unsigned* gbits = reinterpret_cast<const unsigned*>(gscale);
+    float unused_inv;
+    const float t_scale = __uint_as_float(__builtin_amdgcn_readfirstlane(                      // wave-uniform: keep it in an SGPR
+        __float_as_uint(tsg.kind == 2 ? 16.0f : slice_sgn * nfb_dw_pow2_scale(gbits[tsg.gs & 15], unused_inv))));
+    const int out_gs = __builtin_amdgcn_readfirstlane(job.seg[job.tile[pr.a_tile].seg].gs & 15);   // this wave's rows are gradient tiles
 #endif
     float t_cs = 0.f;
     float xs[NFB_DW_NSET][8];
@@ -324,11 +352,15 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
         {
             bf16x8 hi, lo;
 #if NFB_F16
+            t_cs += ((xc[0] + xc[1]) + (xc[2] + xc[3])) + ((xc[4] + xc[5]) + (xc[6] + xc[7]));
             nfb_dw_split_scaled(xc, t_scale, hi, lo);
 #else
-            nfb_dw_split(xc, hi, lo);
-#endif
             t_cs += ((xc[0] + xc[1]) + (xc[2] + xc[3])) + ((xc[4] + xc[5]) + (xc[6] + xc[7]));
+            float xf[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xf[j] = __uint_as_float(__float_as_uint(xc[j]) ^ t_flip);
+            nfb_dw_split(xf, hi, lo);
+#endif
             wr[0] = __builtin_bit_cast(uint4, hi);
             wr[64] = __builtin_bit_cast(uint4, lo);
         }
@@ -372,11 +404,14 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
         nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
         bf16x8 hi, lo;
 #if NFB_F16
+        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
         nfb_dw_split_scaled(xt, t_scale, hi, lo);
 #else
+        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xt[j] = __uint_as_float(__float_as_uint(xt[j]) ^ t_flip);
         nfb_dw_split(xt, hi, lo);
 #endif
-        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
         lds_cvt[wave * 128 + lane] = __builtin_bit_cast(uint4, hi);
         lds_cvt[wave * 128 + lane + 64] = __builtin_bit_cast(uint4, lo);
         __syncthreads();
@@ -395,6 +430,13 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
 
     // D of tile (t, u): lane (h, c), reg r -> row 32 t + (r & 3) + 8 (r >> 2) + 4 h, column 32 u + c
     float* slab = slabs + (int64_t)slice * slab_floats;
+#if NFB_F16
+    float out_scale;
+    (void)nfb_dw_pow2_scale(gbits[out_gs], out_scale);
+    out_scale *= slice_sgn * (1.0f / 16.0f);
+#else
+    const float out_scale = slice_sgn;
+#endif
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
 #pragma unroll
@@ -403,11 +445,7 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
             if (row >= pr.a_valid) continue;
 #pragma unroll
             for (int u = 0; u < 2; ++u)
-#if NFB_F16
                 if (32 * u + c < pr.b_valid) slab[pr.out_off + row * pr.ldo + 32 * u + c] = acc[t][u][r] * out_scale;
-#else
-                if (32 * u + c < pr.b_valid) slab[pr.out_off + row * pr.ldo + 32 * u + c] = acc[t][u][r];
-#endif
         }
     }
     if (t_on && tl.cs_off >= 0) {
@@ -420,7 +458,7 @@ static std::mutex g_dwb_mutex;
 static bool g_dwb_ready[64] = {false};
 
 // called by nf_paper_mlp_bwd_bf16 / _f16 (nf_mlp_bwd.hip) and the lcode counterparts; slabs: n_slices x slab floats of the model;
-// gscale: device {G, 1 / G} (fp16 instantiation only)
+// gscale: max |gradient| per section (float bits) as left by the backward chain (fp16 instantiation only)
 int NFB_DW_NAME(nfb_launch_dw_gemm)(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points,
                                     int64_t pts_per_slice, int n_slices, float* slabs, const float* gscale, nf_stream_t stream) {
     int dev = 0;

@@ -259,16 +259,16 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     nf_bwd_plan(n_points, &pps, &ns);
     nfb_dw_plan(0, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
-    return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS + 16;      // + the gradient scale {G, 1/G, scratch}
+    return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS + 16;      // + max |gradient| per dz section (fp16 kernels)
 }
 
 static NfDwJobTable g_paper_jobs;
 
 // defined in nf_mlp_bf16_bwd.hip / nf_mlp_f16_bwd.hip
 int nfb_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                              const float* gscale, nf_stream_t stream);
+                              float* gscale, nf_stream_t stream);
 int nfb_launch_bwd_chain_f16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                             const float* gscale, nf_stream_t stream);
+                             float* gscale, nf_stream_t stream);
 
 // packed_t (exact f32 chain) | packed_t_bf16 (split-bf16 chain) | packed_t_f16 (split-fp16 chain + dW): exactly one non-NULL
 static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const void* packed_t_f16, bool split_dw,
@@ -303,9 +303,9 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     if (packed_t_f16) {
-        int rc2 = nf_grad_scale(d_raw, n_points * 4, gscale, stream);
-        if (rc2) return rc2;
-        rc2 = nfb_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
+        e = hipMemsetAsync(gscale, 0, 16 * sizeof(float), s);           // max |gradient| per section, filled by the chain
+        if (e != hipSuccess) return (int)e;
+        const int rc2 = nfb_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
         if (rc2) return rc2;
     } else if (packed_t_bf16) {
         const int rc2 = nfb_launch_bwd_chain_bf16(packed_t_bf16, saved, d_raw, n_points, dz, nullptr, stream);

@@ -117,7 +117,7 @@ __device__ __forceinline__ void nfb_zero_tiles(f32x16 (&acc)[8]) {
 
 __global__ void __launch_bounds__(256, 1)
 NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const float* __restrict__ saved, const float* __restrict__ d_raw,
-                                    int64_t n_points, float* __restrict__ dz, const float* __restrict__ gscale) {
+                                    int64_t n_points, float* __restrict__ dz, float* __restrict__ gscale) {
     using namespace nlc;
     __shared__ __attribute__((aligned(16))) char lds[NFB_LDS_BYTES];
     NfbCtx cx;
@@ -131,18 +131,21 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     const int64_t p = p_raw < n_points ? p_raw : n_points - 1;
     const bool live = p_raw < n_points;
     const int64_t n = n_points;
+    // every point runs the chain with its own sign, so that the rounding bias of the 16-bit MFMA accumulation alternates over
+    // points and cancels in the sums over points (see k_paper_mlp_bwd_chain in nf_mlp_bf16_bwd.hip)
+    const float sgn = (c & 1) ? -1.0f : 1.0f;
 #if NFB_F16
     const float* __restrict__ wscale = reinterpret_cast<const float*>(wstream + (size_t)nfb::STREAM_BF16 * 2);
     float wsc[nfb::NL];
 #pragma unroll
     for (int i = 0; i < nfb::NL; ++i) wsc[i] = wscale[nfb::NL + i];
-    float G = gscale[0], invG = gscale[1];
 #pragma unroll
     for (int i = 0; i < nfb::NL; ++i) asm volatile("" : "+s"(wsc[i]));
-    asm volatile("" : "+s"(G), "+s"(invG));
+    unsigned* lmax = reinterpret_cast<unsigned*>(gscale);
+    const unsigned seen = cx.lane < 16 ? __atomic_load_n(lmax + cx.lane, __ATOMIC_RELAXED) : 0u;   // possibly stale: only saves atomics
 #define INV(L_) wsc[L_]
 #else
-    constexpr float G = 1.0f, invG = 1.0f;
+    const float G = sgn, invG = sgn;
 #define INV(L_) 1.0f
 #endif
 
@@ -157,6 +160,16 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
 
     bf16x8 bh[20], bl[20], th[20], tl[20];
+#if NFB_F16
+    // per-point gradient scales (block floating point, nf_mlp_bf16_machinery.inc)
+    float invG;
+    float lm[NFB_GS_DRAW + 1];                                          // this lane's max |gradient| per section (slots: machinery.inc)
+#pragma unroll
+    for (int i = 0; i <= NFB_GS_DRAW; ++i) lm[i] = 0.0f;
+    lm[NFB_GS_DRAW] = live ? fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fmaxf(fabsf(d.z), fabsf(d.w))) : 0.0f;
+    float G = sgn * nfb_pow2_scale(fmaxf(fmaxf(fabsf(d.x), fabsf(d.y)), fabsf(d.z)), invG);  // the rgb gradient of this point
+    invG *= sgn;
+#endif
     {
         float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         if (h == 0 && live) { x[0] = d.x * G; x[1] = d.y * G; x[2] = d.z * G; }
@@ -164,56 +177,71 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
 #pragma unroll
         for (int j = 0; j < 8; ++j) { th[1][j] = (nfb_elt)0.f; tl[1][j] = (nfb_elt)0.f; }
     }
-    bf16x8 sh, sl;                                                     // d sigma k-step
-    {
-        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        if (h == 0 && live) x[0] = d.w * G;
-        nfb_split(x, sh, sl);
-    }
     nfb_wait_vm<nfb::inflight_after(-1)>();
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
     f32x16 acc[8];
-#define NFB_LC_BWD_FINISH(L_, NO_, MASK_, ZSEC_)                                                         \
+    // EXTRA_: a gradient that joins the next layer's operands (d sigma), so that the point's scale covers it
+#if NFB_F16
+#define NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_)                                                              \
+    do {                                                                                                 \
+        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc) : 0.0f);                                  \
+        G = sgn * nfb_pow2_scale(fmaxf(lm[L_], EXTRA_), invG);                                           \
+        invG *= sgn;                                                                                     \
+    } while (0)
+#else
+#define NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_) (void)0
+#endif
+#define NFB_LC_BWD_FINISH(L_, NO_, MASK_, ZSEC_, EXTRA_)                                                 \
     do {                                                                                                 \
         if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                 \
-        if (NFB_F16) nfb_scale<NO_>(acc, INV(L_) * invG);          /* true gradients for dz */            \
+        nfb_scale<NO_>(acc, INV(L_) * invG);                       /* true gradients for dz */            \
         nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
+        NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_);                                                             \
         nfb_to_operands<NO_, false>(acc, bh, bl, 0, G);                                                  \
     } while (0)
     // mask indices: layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
     nfb_zero_tiles<4>(acc);
     NFB_LAYER(0, acc, th, tl);
-    NFB_LC_BWD_FINISH(0, 4, 4, Z_DIR);
+    NFB_LC_BWD_FINISH(0, 4, 4, Z_DIR, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(1, acc, bh, bl);
-    NFB_LC_BWD_FINISH(1, 8, 3, Z_FEAT);
+    NFB_LC_BWD_FINISH(1, 8, 3, Z_FEAT, fabsf(d.w));
     // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight (fc_alpha reads x), gated by layers_xyz.2's ReLU
 #pragma unroll
     for (int s = 0; s < 16; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
-    th[16] = sh; tl[16] = sl;
+    {                                                                  // d sigma k-step, at the scale of dZ_feat's operands
+        float x[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (h == 0 && live) x[0] = d.w * G;
+        nfb_split(x, th[16], tl[16]);
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { th[17][j] = (nfb_elt)0.f; tl[17][j] = (nfb_elt)0.f; }
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(2, acc, th, tl);
-    NFB_LC_BWD_FINISH(2, 8, 2, Z_X2);
+    NFB_LC_BWD_FINISH(2, 8, 2, Z_X2, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(3, acc, bh, bl);
-    NFB_LC_BWD_FINISH(3, 8, 1, Z_X1);
+    NFB_LC_BWD_FINISH(3, 8, 1, Z_X1, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(4, acc, bh, bl);
-    NFB_LC_BWD_FINISH(4, 8, 0, Z_X0);
+    NFB_LC_BWD_FINISH(4, 8, 0, Z_X0, 0.0f);
     nfb_zero_tiles<8>(acc);
     NFB_LAYER(5, acc, bh, bl);                                         // layer1 has no activation: dZ = d(out)
-    if (NFB_F16) nfb_scale<8>(acc, INV(5) * invG);
+    nfb_scale<8>(acc, INV(5) * invG);
     nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L1 * n, 256, p_tile, n);
+    NFB_LC_BWD_RESCALE(5, 8, 0.0f);                                    // only for max |dZ_L1| (the weight-gradient kernel's scale)
+#if NFB_F16
+    nfb_flush_layer_max<NFB_GS_DRAW + 1>(lm, lmax, seen, cx.lane);
+#endif
 #undef NFB_LC_BWD_FINISH
+#undef NFB_LC_BWD_RESCALE
 #undef INV
 }
 
 int NFB_BWD_NAME(nfb_lcode_launch_bwd_chain)(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                                             const float* gscale, nf_stream_t stream) {
+                                             float* gscale, nf_stream_t stream) {
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
     hipLaunchKernelGGL(NFB_BWD_NAME(k_lcode_mlp_bwd_chain), dim3((unsigned)grid), dim3(256), 0, nf_s(stream),

@@ -229,9 +229,9 @@ int nfb_launch_dw_gemm_bf16(int model, const float* dz, const float* d_raw, cons
 int nfb_launch_dw_gemm_f16(int model, const float* dz, const float* d_raw, const float* saved, int64_t n_points, int64_t pts_per_slice,
                            int n_slices, float* slabs, const float* gscale, nf_stream_t stream);
 int nfb_lcode_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                                    const float* gscale, nf_stream_t stream);
+                                    float* gscale, nf_stream_t stream);
 int nfb_lcode_launch_bwd_chain_f16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
-                                   const float* gscale, nf_stream_t stream);
+                                   float* gscale, nf_stream_t stream);
 
 extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
@@ -273,9 +273,9 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     hipError_t e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
     if (packed_t_f16) {
-        int rc = nf_grad_scale(d_raw, n_points * 4, gscale, stream);
-        if (rc) return rc;
-        rc = nfb_lcode_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
+        e = hipMemsetAsync(gscale, 0, 16 * sizeof(float), s);           // max |gradient| per section, filled by the chain
+        if (e != hipSuccess) return (int)e;
+        int rc = nfb_lcode_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
         if (rc) return rc;
         rc = nfb_launch_dw_gemm_f16(1, dz, d_raw, saved, n_points, pps, ns, slabs, gscale, stream);
         if (rc) return rc;

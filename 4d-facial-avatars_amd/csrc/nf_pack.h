@@ -178,36 +178,3 @@ static inline int nf_pack_split_f16(NfPackTable& cache, Build build, const float
     NF_RETURN_LAUNCH();
 }
 
-// ---- per-launch gradient scale of the fp16 training kernels: G = 2^(4 - k) with max |x| = m 2^k, m in [0.5, 1) -- the largest
-// upstream gradient maps into [8, 16), 2^12 below fp16's largest finite value (headroom for growth along the backward chain)
-// and far above its smallest normal.  out[0] = G, out[1] = 1 / G, out[2] = scratch (max bits; must be zero on entry).
-static __global__ void __launch_bounds__(256) k_absmax_bits(const float* __restrict__ x, int64_t n, unsigned* __restrict__ bits) {
-    float m = 0.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(x[i]);
-        if (v < INFINITY) m = fmaxf(m, v);
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > 0.0f) atomicMax(bits, __float_as_uint(m));
-}
-static __global__ void k_make_grad_scale(float* __restrict__ out) {
-    const float amax = __uint_as_float(reinterpret_cast<const unsigned*>(out)[2]);
-    float G = 1.0f;
-    if (amax > 0.0f) {
-        int k;
-        (void)frexpf(amax, &k);
-        int e = 4 - k;
-        e = e < -100 ? -100 : (e > 100 ? 100 : e);
-        G = ldexpf(1.0f, e);
-    }
-    out[0] = G;
-    out[1] = 1.0f / G;
-}
-static inline int nf_grad_scale(const float* x, int64_t n, float* out3, nf_stream_t stream) {
-    hipError_t e = hipMemsetAsync(out3, 0, 4 * sizeof(float), nf_s(stream));
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k_absmax_bits, dim3(256), dim3(256), 0, nf_s(stream), x, n, reinterpret_cast<unsigned*>(out3) + 2);
-    hipLaunchKernelGGL(k_make_grad_scale, dim3(1), dim3(1), 0, nf_s(stream), out3);
-    NF_RETURN_LAUNCH();
-}

@@ -306,7 +306,7 @@ def test_adam_step_moves_live_parameters(hip_lib, gpu):
     assert losses[-1] < losses[0]                    # 3 Adam steps on the same rays/target reduce the loss
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3"])
 def test_training_trajectory_follows_oracle(hip_lib, gpu, precision):
     """Eight Adam steps (coarse+fine, perturb + density noise, latent regulariser) on the HIP path and on the CPU oracle with
     identical data and random draws: the loss trajectories must coincide.  (Adam normalises tiny gradients, so parameters
@@ -355,11 +355,71 @@ def test_training_trajectory_follows_oracle(hip_lib, gpu, precision):
         assert abs(a - b) <= 2e-4 * abs(a) + 1e-6, (losses_o, losses_h)
 
 
+# per-tensor gates of test_training_kernels_vs_fp64_at_training_size.  The bias gradients are sums over 262144 points in which the
+# terms cancel to 1/300 ... 1/12000 of their magnitude (fc_feat.bias), so per-element error is amplified that much: the exact-f32
+# kernels land at 3e-5 there, the fp16 ones below that (measured 1.4e-5), the split-bf16 ones (2^-16 per element) at 1e-4.
+TRAIN_SIZE_GATE = {"f32": 1e-4, "f16": 1e-4, "bf16": 4e-4}
+
+
+@pytest.mark.parametrize("spread", [0, 6])
+@pytest.mark.parametrize("n_rays,s", [(2048, 128), (2047, 127)])
+def test_training_kernels_vs_fp64_at_training_size(hip_lib, gpu, n_rays, s, spread):
+    """BASELINE training size (2048 rays x 128 samples, plus a ragged 2047 x 127): each training arithmetic (exact f32, split
+    fp16, split bf16) -- its own training forward, backward chain and weight-gradient GEMMs -- against fp64 autograd of the
+    oracle MLP evaluated ON THE DEVICE at the ReLU masks that forward saved (mask-consistent: at this size two forwards differ
+    in a few of the 6e8 ReLU decisions, which moves gradients by 1e-3 and says nothing about the kernels).  Upstream gradient
+    at the realistic 1 / (3 n_rays) scale; spread = 6 multiplies it point by point by 10^-U(0, 6), the dynamic range a
+    volume-rendering loss has, which is what the per-point gradient scaling of the fp16 chain is for.  Besides the gates:
+    the fp16 kernels must be at least as accurate as the exact-f32 ones (factor 2 slack), tensor class by tensor class."""
+    import nerf
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    g = torch.Generator().manual_seed(29)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 9, n_rays, 29)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    d_raw = torch.randn((n_rays, s, 4), generator=g) * (1.0 / (n_rays * 3))
+    if spread:
+        d_raw = d_raw * torch.pow(10.0, -spread * torch.rand((n_rays, s, 1), generator=g))
+    p = c["p_fine"]
+    m = U.make_model(nerf, p, gpu)
+    hw = m.hip_weights()
+    pk = hw.get()
+    cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    dv = lambda t: t.to(gpu)
+    n_pts = n_rays * s
+    x64 = O.encode_points(dv(ro).double(), dv(rd).double(), dv(z).double(), O.NEAR, O.FAR)
+    worst, saved_act = {}, {}
+    for mode in ("f32", "f16", "bf16"):
+        _, saved = ops.paper_mlp_fwd_train(pk, cond, dv(ro), dv(rd), dv(z), packed_b=hw.get_bf16() if mode == "bf16" else None,
+                                           packed_h=hw.get_f16() if mode == "f16" else None)
+        grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, dv(z), dv(d_raw), saved, split={"f32": False, "f16": "f16", "bf16": True}[mode])
+        assert all(bool(torch.isfinite(x).all()) for x in grads if x is not None) and bool(torch.isfinite(g_lat).all())
+        masks = [saved_section(saved[0], k, n_pts) > 0 for k in RELU_ORDER]
+        saved_act[mode] = saved[0][:2256 * n_pts]
+        pp = {k: v.to(gpu).double().clone().requires_grad_(True) for k, v in p.items()}
+        lat = c["latent"].to(gpu).double().clone().requires_grad_(True)
+        out = O.paper_mlp(pp, x64, c["expr"].to(gpu).double(), lat, masks=masks)
+        out.backward(dv(d_raw).reshape(-1, 4).double())
+        errs = {k: rel_l2(gh, pp[k].grad) for k, gh in zip(ops.PAPER_KEYS, grads) if gh is not None}
+        errs["latent"] = rel_l2(g_lat, lat.grad)
+        worst[mode] = {"weight": max(v for k, v in errs.items() if k.endswith("weight")),
+                       "bias": max(v for k, v in errs.items() if k.endswith("bias")), "latent": errs["latent"]}
+        print(f"{mode:4s} {n_rays}x{s} spread 1e-{spread}: worst weight {worst[mode]['weight']:.2e} bias {worst[mode]['bias']:.2e} "
+              f"latent {worst[mode]['latent']:.2e}")
+        for k, v in errs.items():
+            assert v < TRAIN_SIZE_GATE[mode], (mode, k, v)
+        del pp, lat, out, masks, saved, grads
+    for cls in ("weight", "bias", "latent"):
+        assert worst["f16"][cls] <= 2 * worst["f32"][cls] + 1e-6, (cls, worst)
+    a, b = saved_act["f32"], saved_act["f16"]
+    assert float((a - b).abs().max()) <= 2e-5 * (1 + float(a.abs().max()))        # saved activations: f32 rounding apart
+
+
 @pytest.mark.parametrize("n_rays,s", [(2048, 128), (2047, 127), (2048, 64)])
 def test_split_dw_gemm_matches_exact_at_training_size(hip_lib, gpu, n_rays, s):
     """BASELINE training sizes (configs[2]: 2048 rays, 64 coarse / 128 fine samples; plus a ragged size whose last
-    16-point stage is partial): on the SAME saved activations and dZ, the split-bf16 weight-gradient kernel (42 slices,
-    16-wave bundles) must agree with the exact-f32 one (28 slices) to the split's 2^-16 class, tensor by tensor."""
+    16-point stage is partial): on the SAME saved activations and dZ, the split-bf16 weight-gradient kernel (one 16-wave
+    workgroup per CU) must agree with the exact-f32 one (28 slices) to the split's 2^-16 class, tensor by tensor."""
     import nerf
     from nerf import ops
     c = C.build_case("train_rand_64_64")
