@@ -349,7 +349,7 @@ extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_b
 }
 
 // Same on fp16 operand pairs ("f16x3": fp32-class accuracy at the split-bf16 speed): dX chain (nf_mlp_f16_bwd.hip) and weight-
-// gradient GEMMs (nf_mlp_f16_dw.hip), gradients scaled by a per-launch power of two chosen from max |d_raw|.  `saved` must
+// gradient GEMMs (nf_mlp_f16_dw.hip), gradients in block floating point (a power-of-two scale per point and layer in the chain, per dZ section in the GEMMs).  `saved` must
 // come from nf_paper_mlp_fwd_train_f16; packed_t_f16 from nf_paper_pack_bwd_f16.
 extern "C" int nf_paper_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* cond, const float* saved,
                                     const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,

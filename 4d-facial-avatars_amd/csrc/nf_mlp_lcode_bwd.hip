@@ -238,7 +238,7 @@ extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
     nf_bwd_plan(n_points, &pps, &ns);
     nfb_dw_plan(1, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
-    return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS + 16;      // + gradient scale {G, 1/G, scratch}
+    return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS + 16;      // + max |gradient| per dz section (fp16 kernels)
 }
 
 static NfDwJobTable g_lcode_jobs;

@@ -28,7 +28,7 @@ PAPER_KEYS = (
 # The switch applies to inference AND to a training step: under "bf16x3" the training forward, the dX chain and the
 # weight-gradient GEMMs all run on the split-bf16 kernels (paper_mlp_bwd(..., exact_dw=True) keeps the dW GEMMs exact).
 # "f16x3" = split-fp16: the same three-MFMA scheme on fp16 pairs (22 operand bits, per-layer power-of-two weight scales,
-# per-launch gradient scale): fp32-class accuracy at the bf16x3 speed, for inference and for all three training GEMM kernels
+# per-point block-floating-point gradient scales): fp32-class accuracy at the bf16x3 speed, for inference and for all three training GEMM kernels
 # of both model families.
 _VALID_PRECISIONS = ("f32", "bf16x3", "f16x3")
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")

@@ -101,7 +101,7 @@ int nf_paper_mlp_fwd_f16(const void* packed_f16, const float* cond, const float*
 /* training on the split-fp16 kernels ("f16x3": the three training GEMM kernels -- activation-saving forward, dX chain,
  * weight-gradient GEMMs -- at fp32-class accuracy on the 16-bit matrix pipe).  nf_paper_mlp_fwd_train_f16 fills `saved` like
  * nf_paper_mlp_fwd_train_bf16; nf_paper_mlp_bwd_f16 = nf_paper_mlp_bwd with the chain and the dW GEMMs on fp16 pairs, gradients
- * carried times a per-launch power of two chosen from max |d_raw| (workspace as nf_paper_bwd_workspace_floats).           */
+ * carried in block floating point (one power-of-two scale per point and layer; workspace as nf_paper_bwd_workspace_floats). */
 int nf_paper_mlp_fwd_train_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
 size_t nf_paper_packed_bwd_f16_bytes(void);
