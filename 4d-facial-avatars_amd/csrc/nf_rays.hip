@@ -38,6 +38,54 @@ extern "C" int nf_ray_bundle(int height, int width, float fx, float fy, float cx
     NF_RETURN_LAUNCH();
 }
 
+// K1 for a training batch: the rays of `n` selected pixels only (sel[i] = {row, col}, int64 as torch.multinomial / indexing
+// hands them over), with the same arithmetic as k_ray_bundle -- bit-identical to gathering from the full bundle -- plus the
+// gathers of the target pixels (image (H, W, C)) and of the background prior (H, W, 3) in the same pass.  Replaces the
+// reference's full-frame get_ray_bundle + four index gathers per iteration (train_transformed_rays.py:302, 325-330).
+__global__ void __launch_bounds__(256) k_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h,
+                                                   const float* __restrict__ c2w, int rs, const int64_t* __restrict__ sel, int64_t n,
+                                                   const float* __restrict__ image, int channels, const float* __restrict__ bg,
+                                                   float* __restrict__ ro, float* __restrict__ rd, float* __restrict__ target,
+                                                   float* __restrict__ bg_out, int* __restrict__ bad) {
+    const float r00 = c2w[0], r01 = c2w[1], r02 = c2w[2], t0 = c2w[3];
+    const float r10 = c2w[rs + 0], r11 = c2w[rs + 1], r12 = c2w[rs + 2], t1 = c2w[rs + 3];
+    const float r20 = c2w[2 * rs + 0], r21 = c2w[2 * rs + 1], r22 = c2w[2 * rs + 2], t2 = c2w[2 * rs + 3];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t h = sel[2 * i], w = sel[2 * i + 1];
+        if (h < 0 || h >= height || w < 0 || w >= width) {            // reported to the host; the lane writes pixel (0, 0)
+            atomicOr(bad, 1);
+            h = 0; w = 0;
+        }
+        const float dx = nf_div(nf_sub((float)w, cx_w), fx);
+        const float dy = -nf_div(nf_sub((float)h, cy_h), fy);
+        const float dz = -1.0f;
+        float* o = rd + i * 3;
+        o[0] = nf_add(nf_add(nf_mul(dx, r00), nf_mul(dy, r01)), nf_mul(dz, r02));
+        o[1] = nf_add(nf_add(nf_mul(dx, r10), nf_mul(dy, r11)), nf_mul(dz, r12));
+        o[2] = nf_add(nf_add(nf_mul(dx, r20), nf_mul(dy, r21)), nf_mul(dz, r22));
+        float* q = ro + i * 3;
+        q[0] = t0; q[1] = t1; q[2] = t2;
+        const int64_t pix = h * width + w;
+        if (target)
+            for (int c = 0; c < channels; ++c) target[i * channels + c] = image[pix * channels + c];
+        if (bg_out)
+            for (int c = 0; c < 3; ++c) bg_out[i * 3 + c] = bg[pix * 3 + c];
+    }
+}
+
+extern "C" int nf_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h, const float* c2w, int c2w_row_stride,
+                            const int64_t* sel, int64_t n, const float* image, int channels, const float* bg, float* ro, float* rd,
+                            float* target, float* bg_out, int* bad_flag, nf_stream_t stream) {
+    if (n == 0) return 0;
+    if (height <= 0 || width <= 0 || n < 0 || !c2w || !sel || !ro || !rd || !bad_flag || c2w_row_stride < 4 ||
+        (target && (!image || channels <= 0)) || (bg_out && !bg))
+        return NF_EINVAL;
+    const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+    hipLaunchKernelGGL(k_ray_batch, dim3(grid), dim3(256), 0, nf_s(stream), height, width, fx, fy, cx_w, cy_h, c2w, c2w_row_stride,
+                       sel, n, image, channels, bg, ro, rd, target, bg_out, bad_flag);
+    NF_RETURN_LAUNCH();
+}
+
 // ---------------------------------------------------------------------------------------------
 // K2: coarse depths (reference nerf/train_utils.py:56-76).
 //   z = near*(1-t) + far*t with t = the caller's linspace(0,1,Nc) table;

@@ -95,13 +95,12 @@ def main(argv=None):
         img_idx = int(i_train[k])
         target_img, pose, expr = stager.fetch(img_idx)
         latent = latent_codes[k]
-        ro, rd = nerf.get_ray_bundle(H, W, intrinsics, pose)
         sel = coords[torch.multinomial(maps[k], n_rays, replacement=False)]
         if first_draw is None:
             first_draw = (img_idx, sel[:8].clone())
-        ro, rd = ro[sel[:, 0], sel[:, 1], :], rd[sel[:, 0], sel[:, 1], :]
-        target = target_img[sel[:, 0], sel[:, 1], :]
-        bg = background[sel[:, 0], sel[:, 1], :] if background is not None else None
+        # rays, target pixels and background prior of the selected pixels only, one kernel (TR:302 builds the full 512 x 512
+        # bundle every iteration and gathers four times, TR:325-330)
+        ro, rd, target, bg = nerf.get_ray_batch(H, W, intrinsics, pose, sel, target_img, background)
         rgb_c, _, _, rgb_f, _, _, _ = nerf.run_one_iter_of_nerf(
             H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="train", encode_position_fn=enc_xyz,
             encode_direction_fn=enc_dir, expressions=expr, background_prior=bg, latent_code=latent)

@@ -62,6 +62,15 @@ def get_ray_bundle(height: int, width: int, intrinsics, tform_cam2world: torch.T
     return ops.ray_bundle(int(height), int(width), fx, fy, cx, cy, tform_cam2world)
 
 
+def get_ray_batch(height: int, width: int, intrinsics, tform_cam2world: torch.Tensor, select_inds: torch.Tensor, target_img=None,
+                  background=None, check: bool = False):
+    """Training-batch form of get_ray_bundle (not in the reference: the launcher's replacement for TR:302 + TR:325-330):
+    rays, target pixels and background prior of the pixels select_inds (n, 2) = {row, col} only, one kernel (nf_ray_batch).
+    Rays are bit-identical to get_ray_bundle(...)[select_inds[:, 0], select_inds[:, 1]]."""
+    fx, fy, cx, cy = _intrinsics4(intrinsics)
+    return ops.ray_batch(int(height), int(width), fx, fy, cx, cy, tform_cam2world, select_inds, target_img, background, check)
+
+
 class PositionalEncoder:
     """Callable returned by get_embedding_function.  It is tagged with its parameters so that
     run_one_iter_of_nerf can recognise it and run the encoding inside the fused MLP kernel instead of

@@ -89,6 +89,40 @@ def ray_bundle(height: int, width: int, fx: float, fy: float, cx: float, cy: flo
     return ro, rd
 
 
+def ray_batch(height: int, width: int, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor, sel: torch.Tensor,
+              image: Optional[torch.Tensor] = None, background: Optional[torch.Tensor] = None, check: bool = False):
+    """Rays of the selected pixels only (sel (n, 2) int64 {row, col}) -- bit-identical to get_ray_bundle(...)[sel[:, 0], sel[:, 1]]
+    -- plus the target pixels of `image` (H, W, C) and the background prior (H, W, 3) at the same pixels, in one launch
+    (TR:302, 325-330).  Returns (ro, rd, target | None, bg | None).  check=True reads the out-of-range flag back (host sync)."""
+    c2w = c2w if (c2w.dtype == torch.float32 and c2w.stride(-1) == 1) else c2w.to(torch.float32).contiguous()
+    if sel.dtype != torch.int64 or sel.dim() != 2 or sel.shape[1] != 2:
+        raise ValueError("sel must be an (n, 2) int64 tensor of {row, col}")
+    sel, image, background = sel.contiguous(), _c(image), _c(background)
+    dev = H.require_device(c2w, image, background)
+    if sel.device != dev:
+        raise RuntimeError("ray_batch: select_inds must live on the device of the pose")
+    n = int(sel.shape[0])
+    if image is not None and (image.dim() != 3 or tuple(image.shape[:2]) != (height, width) or image.dtype != torch.float32):
+        raise ValueError("image must be a float32 (H, W, C) tensor")
+    if background is not None and (tuple(background.shape) != (height, width, 3) or background.dtype != torch.float32):
+        raise ValueError("background must be a float32 (H, W, 3) tensor")
+    ch = int(image.shape[2]) if image is not None else 0
+    ro = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    rd = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    target = torch.empty((n, ch), dtype=torch.float32, device=dev) if image is not None else None
+    bg = torch.empty((n, 3), dtype=torch.float32, device=dev) if background is not None else None
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    cx_w = float(np.float32(np.float64(width) * np.float64(cx)))
+    cy_h = float(np.float32(np.float64(height) * np.float64(cy)))
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_ray_batch(height, width, float(np.float32(fx)), float(np.float32(fy)), cx_w, cy_h, H.ptr(c2w),
+                                     int(c2w.stride(0)), H.ptr(sel), n, H.ptr(image), ch, H.ptr(background), H.ptr(ro), H.ptr(rd),
+                                     H.ptr(target), H.ptr(bg), H.ptr(flag), H.stream_ptr(dev)), "nf_ray_batch")
+    if check and int(flag.item()):
+        raise IndexError("ray_batch: a selected pixel lies outside the image")
+    return ro, rd, target, bg
+
+
 # ---------------------------------------------------------------------------------------- K2
 def sample_coarse(n_rays: int, n_coarse: int, near: float, far: float, device, t_rand: Optional[torch.Tensor] = None):
     t_rand = _c(t_rand)

@@ -236,8 +236,8 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     optim = torch.optim.Adam(params, lr=5e-4, fused=True)      # same update rule as TR:193-199, one multi-tensor kernel
     reducer = D.GradientAllReducer(params)
     g = torch.Generator().manual_seed(7)
-    background = torch.rand((H, W, 3), generator=g).to(dev).view(-1, 3)
-    target = torch.rand((H, W, 3), generator=g).to(dev).view(-1, 3)
+    background = torch.rand((H, W, 3), generator=g).to(dev)
+    target = torch.rand((H, W, 3), generator=g).to(dev)
     torch.manual_seed(D.rank_seed(1234))
     n_it = args.steps + args.warmup
     frame_ids = torch.randint(0, n_train, (n_it,)).tolist()
@@ -245,13 +245,14 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     exprs = [(0.5 * torch.randn(76)).to(dev) for _ in frame_ids]
 
     def step(i):
-        ro, rd = nerf.get_ray_bundle(H, W, INTRINSICS, poses[i])
         idx = torch.randperm(H * W, device=dev)[:n_rays]
+        sel = torch.stack((idx // W, idx % W), dim=-1)
+        # rays + target pixels + background prior of the selected pixels in one kernel (the launcher's form of TR:302, 325-330)
+        ro, rd, tgt, bg = nerf.get_ray_batch(H, W, INTRINSICS, poses[i], sel, target, background)
         latent = latent_codes[frame_ids[i]]
-        out = nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro.view(-1, 3)[idx], rd.view(-1, 3)[idx], opt,
+        out = nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro, rd, opt,
                                         mode="train", encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
-                                        expressions=exprs[i], background_prior=background[idx], latent_code=latent)
-        tgt = target[idx]
+                                        expressions=exprs[i], background_prior=bg, latent_code=latent)
         loss = (torch.nn.functional.mse_loss(out[0], tgt) + torch.nn.functional.mse_loss(out[3], tgt)
                 + 10 * 0.0005 * torch.norm(latent))
         loss.backward()

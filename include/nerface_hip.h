@@ -37,6 +37,14 @@ const char* nf_build_info(void);             /* "gfx950 <compiler> <date>"      
 int nf_ray_bundle(int height, int width, float fx, float fy, float cx_w, float cy_h,
                   const float* c2w, int c2w_row_stride, float* ro, float* rd, nf_stream_t stream);
 
+/* K1 for a training batch -- replaces the full-frame get_ray_bundle plus the index gathers of one iteration
+ * (train_transformed_rays.py:302, 325-330).  sel: (n, 2) int64 {row, col}; ro, rd: (n, 3), bit-identical to rows of
+ * nf_ray_bundle's output; target (n, channels) gathered from image (H, W, channels) and bg_out (n, 3) from bg (H, W, 3),
+ * each optional (NULL).  bad_flag: one zeroed int on the device, set to 1 if a selected pixel lies outside the image.   */
+int nf_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h, const float* c2w, int c2w_row_stride,
+                 const int64_t* sel, int64_t n, const float* image, int channels, const float* bg, float* ro, float* rd,
+                 float* target, float* bg_out, int* bad_flag, nf_stream_t stream);
+
 /* ---- K2: stratified coarse depths -- replaces T:56-76 -------------------------------------------- */
 /* z: (n_rays, n_coarse).  t_vals: (n_coarse) = the caller's torch.linspace(0,1,n_coarse) table (T:50-55;
  * passing the table keeps torch's own linspace rounding).  t_rand NULL => perturb off.  Bit-exact.    */

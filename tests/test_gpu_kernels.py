@@ -25,6 +25,32 @@ def test_ray_bundle_bit_exact(hip_lib, gpu):
     assert np.array_equal(rd_s.cpu().numpy(), g["rd_scalar"])
 
 
+def test_ray_batch_equals_gathers_from_the_full_bundle(hip_lib, gpu):
+    """The training-batch kernel (launcher's replacement for TR:302 + TR:325-330): rays of selected pixels must be the oracle's
+    full bundle at these pixels bit for bit; target / background gathers must equal torch indexing; RGBA targets, duplicate
+    and corner pixels, an empty selection and an out-of-range pixel (reported, not silently wrapped)."""
+    import nerf
+    pose = O.frame_pose(42)
+    g = torch.Generator().manual_seed(5)
+    for (h, w, ch, n) in [(512, 512, 3, 2048), (37, 53, 4, 300), (1, 1, 3, 2)]:
+        ro_o, rd_o = O.ray_bundle(h, w, O.INTRINSICS, pose)
+        sel = torch.stack((torch.randint(0, h, (n,), generator=g), torch.randint(0, w, (n,), generator=g)), dim=-1)
+        sel[0] = torch.tensor([h - 1, w - 1])
+        sel[-1] = sel[0]
+        img, bg = torch.rand((h, w, ch), generator=g), torch.rand((h, w, 3), generator=g)
+        ro, rd, tgt, b = nerf.get_ray_batch(h, w, O.INTRINSICS, pose.to(gpu), sel.to(gpu), img.to(gpu), bg.to(gpu), check=True)
+        assert torch.equal(rd.cpu(), rd_o[sel[:, 0], sel[:, 1]]) and torch.equal(ro.cpu(), ro_o[sel[:, 0], sel[:, 1]])
+        assert torch.equal(tgt.cpu(), img[sel[:, 0], sel[:, 1]]) and torch.equal(b.cpu(), bg[sel[:, 0], sel[:, 1]])
+        ro2, rd2, t2, b2 = nerf.get_ray_batch(h, w, O.INTRINSICS, pose.to(gpu), sel.to(gpu))
+        assert t2 is None and b2 is None and torch.equal(rd2, rd)
+    ro, rd, tgt, b = nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.zeros((0, 2), dtype=torch.int64, device=gpu))
+    assert ro.shape == (0, 3) and rd.shape == (0, 3)
+    with pytest.raises(IndexError):
+        nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([[3, 8]], device=gpu), check=True)
+    with pytest.raises(ValueError):
+        nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([[3.0, 1.0]], device=gpu))
+
+
 @pytest.mark.parametrize("nc", [64, 5, 1, 192])
 def test_sample_coarse_bit_exact(hip_lib, gpu, nc):
     from nerf import ops
