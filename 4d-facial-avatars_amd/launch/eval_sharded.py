@@ -70,7 +70,7 @@ def _main(argv=None):
     ap.add_argument("--savedir", type=str, required=True)
     ap.add_argument("--save-disparity-image", action="store_true")
     ap.add_argument("--save-normals", action="store_true", help="also write the cleaned normal map of EV:469-471 (savedir/normals)")
-    ap.add_argument("--precision", choices=["f32", "bf16x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "f16x3", "bf16x3"], default="f32",
                     help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; bf16x3 = split-bf16 kernels, 3x faster, "
                          "within the 1e-4 dB PSNR gate (tests/test_gpu_bf16.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"))

@@ -450,11 +450,12 @@ def test_split_dw_gemm_matches_exact_at_training_size(hip_lib, gpu, n_rays, s):
     assert all(a2 is None or torch.equal(a, a2) for a, a2 in zip(g_s, g_s2)) and torch.equal(lat_s, lat_s2)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "bf16x3", "f16x3"])
 def test_full_size_training_step_properties(hip_lib, gpu, precision):
     """BASELINE configs[2] at its full size (2048 rays of a 512x512 frame, 64+64 samples, noise 0.1, perturb): the backward is
     linear in the upstream gradient, so doubling the loss must double every gradient EXACTLY (power-of-two scaling commutes
-    with fp32 rounding and with the hi/lo bf16 split); repeating the step with the same random draws must reproduce every
+    with fp32 rounding, with the hi/lo bf16 split, and with the fp16 kernels' block floating point, whose per-point scales
+    halve when the gradients double); repeating the step with the same random draws must reproduce every
     gradient bit for bit (fixed-order slab reduction, no atomics); every live tensor gets a finite, non-zero gradient."""
     import nerf
     c = C.build_case("train_rand_64_64")
