@@ -4,8 +4,10 @@ from __future__ import annotations
 import os
 import sys
 
-import numpy as np
-import torch
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL peer mappings (must be set before the HIP runtime starts)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 import yaml
 
 PKG = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -35,6 +35,10 @@ import os
 import sys
 import time
 
+# the host driver of this pool only supports dmabuf IPC: without this RCCL's peer mappings fail at N > 1 (exported by the image
+# already; set here too so that a bare `python -m torch.distributed.run ... bench.py` from a clean shell works)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.join(ROOT, "4d-facial-avatars_amd")
 for _p in (ROOT, PKG):
