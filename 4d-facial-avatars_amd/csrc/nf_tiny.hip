@@ -239,9 +239,20 @@ __global__ void __launch_bounds__(256) k_tiny_grad_unpack(const float* __restric
 
 extern "C" size_t nf_tiny_grad_floats(void) { return (size_t)nft::GRAD_FLOATS; }
 
+// point slices of the weight-gradient kernel: the three jobs of the tiny model fit ONE workgroup (a wave per job), so the slice
+// count is the grid -- one workgroup per CU (256 slices of >= 256 points) instead of the 28 slices the big models' plan gives
+// (28 workgroups on 256 CUs: 1.38 ms for a 64 x 64 x 32 image, most of a training iteration)
+static inline void nf_tiny_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_slices) {
+    int64_t pps = (n_points + 255) / 256;
+    pps = (pps + 15) / 16 * 16;
+    if (pps < 256) pps = 256;
+    *pts_per_slice = pps;
+    *n_slices = (int)((n_points + pps - 1) / pps);
+}
+
 extern "C" size_t nf_tiny_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns;
-    nf_bwd_plan(n_points, &pps, &ns);
+    nf_tiny_bwd_plan(n_points, &pps, &ns);
     return (size_t)nft::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nft::SLAB;
 }
 
@@ -255,7 +266,7 @@ extern "C" int nf_tiny_mlp_bwd(const float* packed_t, const float* saved, const 
     const int rcj = g_tiny_jobs.get(N_JOBS, nf_tiny_dw_jobs, &jobs);
     if (rcj) return rcj;
     int64_t pps; int ns;
-    nf_bwd_plan(n_points, &pps, &ns);
+    nf_tiny_bwd_plan(n_points, &pps, &ns);
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB;

@@ -350,10 +350,25 @@ def bench_tiny(dev, steps=20):
     torch.cuda.synchronize()
     ms_train = 1e3 * (time.perf_counter() - t0) / steps
     assert bool(torch.isfinite(loss))
+    # the same loop body captured once in a HIP graph and replayed (tiny_nerf.GraphedTinyTrainer; jitter drawn on the device)
+    model_g = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
+    model_g.load_state_dict(model.state_dict())
+    trainer = TN.GraphedTinyTrainer(model_g, torch.optim.Adam(model_g.parameters(), lr=5e-3, capturable=True), 64, 64, focal, 2.0, 6.0, 32, dev)
+    for _ in range(3):
+        trainer.step(pose_d, target)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5 * steps):
+        loss_g = trainer.step(pose_d, target)
+    torch.cuda.synchronize()
+    ms_graph = 1e3 * (time.perf_counter() - t0) / (5 * steps)
+    assert bool(torch.isfinite(loss_g))
     res = {"workload": "configs[0]: tiny_nerf 64x64 image, 32 samples per ray, VeryTinyNerfModel (63-128-128-4), forward",
            "value": 4096 / (ms * 1e-3), "unit": "rays/s", "ms_per_image": ms, "images": steps,
            "train": {"ms_per_iter": ms_train, "value": 4096 / (ms_train * 1e-3), "unit": "rays/s",
-                     "what": "forward + mse + backward (HIP kernels) + Adam per 64x64 image (TN:282-302)"},
+                     "what": "forward + mse + backward (HIP kernels) + Adam per 64x64 image (TN:282-302)",
+                     "hip_graph": {"ms_per_iter": ms_graph, "value": 4096 / (ms_graph * 1e-3), "unit": "rays/s",
+                                   "what": "the same iteration captured once in a HIP graph and replayed (GraphedTinyTrainer)"}},
            "note": "host-launch bound on the device (ray bundle + two kernels per image of 4096 rays)"}
     return res, ({k: v.detach().cpu() for k, v in model.state_dict().items()}, pose, focal)
 

@@ -121,3 +121,59 @@ def test_render_volume_density_matches_oracle(hip_lib, gpu):
     assert ((w[..., None] * torch.sigmoid(raw[..., :3].double())).sum(-2) - rgb.cpu().double()).abs().max() < 3e-6
     assert ((w * depth.double()).sum(-1) - dmap.cpu().double()).abs().max() < 2e-5
     assert (w.sum(-1) - acc.cpu().double()).abs().max() < 3e-6
+
+
+def test_graphed_tiny_trainer_equals_eager_steps(hip_lib, gpu):
+    """The HIP-graph form of the tiny trainer's loop body (TN:282-302): with the caller's jitter, N replayed iterations must
+    leave the parameters exactly where N eager iterations (same kernels, same Adam) leave them, on changing poses and
+    targets; with the device-side draw it must train (loss falls) and keep drawing fresh random numbers per replay."""
+    sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
+    import tiny_nerf as TN
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    g = torch.Generator().manual_seed(23)
+    poses = []
+    for f in (3, 11, 40, 77, 5, 19):
+        p = O.frame_pose(f)
+        p[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+        poses.append(p.to(gpu))
+    targets = [torch.rand((64, 64, 3), generator=g).to(gpu) for _ in poses]
+    jitters = [torch.rand((64, 64, 32), generator=g).to(gpu) for _ in poses]
+
+    def make():
+        m = TN.VeryTinyNerfModel(num_encoding_functions=10).to(gpu)
+        m.load_state_dict(O.tiny_init_params(9458))
+        return m, torch.optim.Adam(m.parameters(), lr=5e-3, capturable=True)
+
+    # eager reference: the same iteration body, one launch at a time
+    m_e, opt_e = make()
+    tr_e = TN.GraphedTinyTrainer(m_e, opt_e, 64, 64, focal, 2.0, 6.0, 32, gpu)
+    tr_e._own_jitter = False
+    losses_e = []
+    tr_e.pose.copy_(poses[0]); tr_e.target.copy_(targets[0]); tr_e.jitter.copy_(jitters[0])
+    for _ in range(3):                                           # the graphed trainer's warm-up iterations (they train, too)
+        tr_e._iteration()
+    for p, t, j in zip(poses, targets, jitters):
+        tr_e.pose.copy_(p); tr_e.target.copy_(t); tr_e.jitter.copy_(j)
+        tr_e._iteration()
+        losses_e.append(float(tr_e.loss))
+    # graphed: 3 warm-up iterations on the first inputs (side stream), capture (records only), then one replay per call
+    m_g, opt_g = make()
+    tr_g = TN.GraphedTinyTrainer(m_g, opt_g, 64, 64, focal, 2.0, 6.0, 32, gpu, warmup=3)
+    state0 = {k: v.clone() for k, v in m_g.state_dict().items()}
+    losses_g = [float(tr_g.step(p, t, j)) for p, t, j in zip(poses, targets, jitters)]
+    assert tr_g.graph is not None
+    for k, v in m_g.state_dict().items():
+        assert not torch.equal(v, state0[k]), k
+        assert torch.equal(v, m_e.state_dict()[k]), k
+    assert losses_g == losses_e, (losses_g, losses_e)
+    with pytest.raises(ValueError):
+        tr_g.step(poses[0], targets[0])                          # jitter source is fixed at capture
+    # device-side jitter: trains on one view, and the draws differ from replay to replay
+    m_d, opt_d = make()
+    tr_d = TN.GraphedTinyTrainer(m_d, opt_d, 64, 64, focal, 2.0, 6.0, 32, gpu)
+    first = float(tr_d.step(poses[0], targets[0]))
+    j1 = tr_d.jitter.clone()
+    for _ in range(40):
+        last = float(tr_d.step(poses[0], targets[0]))
+    assert not torch.equal(j1, tr_d.jitter) and 0.0 <= float(tr_d.jitter.min()) and float(tr_d.jitter.max()) < 1.0
+    assert last < first, (first, last)
