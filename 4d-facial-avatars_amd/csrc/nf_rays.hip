@@ -91,21 +91,25 @@ extern "C" int nf_ray_batch(int height, int width, float fx, float fy, float cx_
 //   z = near*(1-t) + far*t with t = the caller's linspace(0,1,Nc) table;
 //   perturb: z = lower + (upper-lower)*t_rand with mid-point brackets.  No FMA contraction.
 // ---------------------------------------------------------------------------------------------
+//   lindisp (T:65-66): z = 1 / (1/near * (1 - t) + 1/far * t), every operation a separately rounded fp32 one, in that order.
+template <bool LINDISP>
 __device__ __forceinline__ float nf_coarse_z(float t, float near_z, float far_z) {
+    if (LINDISP) return nf_div(1.0f, nf_add(nf_mul(nf_div(1.0f, near_z), nf_sub(1.0f, t)), nf_mul(nf_div(1.0f, far_z), t)));
     return nf_add(nf_mul(near_z, nf_sub(1.0f, t)), nf_mul(far_z, t));
 }
 
+template <bool LINDISP>
 __global__ void __launch_bounds__(256) k_sample_coarse(int64_t n_rays, int nc, float near_z, float far_z,
                                                        const float* __restrict__ t_vals,
                                                        const float* __restrict__ t_rand, float* __restrict__ z) {
     const int64_t total = n_rays * nc;
     for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (int64_t)gridDim.x * blockDim.x) {
         const int i = (int)(p % nc);
-        const float zi = nf_coarse_z(t_vals[i], near_z, far_z);
+        const float zi = nf_coarse_z<LINDISP>(t_vals[i], near_z, far_z);
         float out = zi;
         if (t_rand) {
-            const float zl = i > 0 ? nf_coarse_z(t_vals[i - 1], near_z, far_z) : zi;
-            const float zu = i < nc - 1 ? nf_coarse_z(t_vals[i + 1], near_z, far_z) : zi;
+            const float zl = i > 0 ? nf_coarse_z<LINDISP>(t_vals[i - 1], near_z, far_z) : zi;
+            const float zu = i < nc - 1 ? nf_coarse_z<LINDISP>(t_vals[i + 1], near_z, far_z) : zi;
             const float lower = i > 0 ? nf_mul(0.5f, nf_add(zi, zl)) : zi;
             const float upper = i < nc - 1 ? nf_mul(0.5f, nf_add(zu, zi)) : zi;
             out = nf_add(lower, nf_mul(nf_sub(upper, lower), t_rand[p]));
@@ -114,15 +118,24 @@ __global__ void __launch_bounds__(256) k_sample_coarse(int64_t n_rays, int nc, f
     }
 }
 
-extern "C" int nf_sample_coarse(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
-                                const float* t_rand, float* z, nf_stream_t stream) {
+extern "C" int nf_sample_coarse_ex(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
+                                   const float* t_rand, int lindisp, float* z, nf_stream_t stream) {
     if (n_rays == 0) return 0;                       // nothing to do (empty tensors have NULL data pointers)
     if (n_rays < 0 || n_coarse <= 0 || !z || !t_vals) return NF_EINVAL;
     const int64_t total = n_rays * n_coarse;
     const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-    hipLaunchKernelGGL(k_sample_coarse, dim3(grid), dim3(256), 0, nf_s(stream), n_rays, n_coarse, near_z, far_z, t_vals,
-                       t_rand, z);
+    if (lindisp)
+        hipLaunchKernelGGL(k_sample_coarse<true>, dim3(grid), dim3(256), 0, nf_s(stream), n_rays, n_coarse, near_z, far_z, t_vals,
+                           t_rand, z);
+    else
+        hipLaunchKernelGGL(k_sample_coarse<false>, dim3(grid), dim3(256), 0, nf_s(stream), n_rays, n_coarse, near_z, far_z, t_vals,
+                           t_rand, z);
     NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_sample_coarse(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
+                                const float* t_rand, float* z, nf_stream_t stream) {
+    return nf_sample_coarse_ex(n_rays, n_coarse, near_z, far_z, t_vals, t_rand, 0, z, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -26,6 +26,7 @@ _PROTOTYPES = {
     "nf_ray_bundle": (C.c_int, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _P, _P]),
     "nf_ray_batch": (C.c_int, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "nf_sample_coarse": (C.c_int, [_L, _I, _F, _F, _P, _P, _P, _P]),
+    "nf_sample_coarse_ex": (C.c_int, [_L, _I, _F, _F, _P, _P, _I, _P, _P]),
     "nf_posenc": (C.c_int, [_P, _L, _I, _I, _I, _P, _P]),
     "nf_paper_packed_floats": (_Z, []),
     "nf_paper_cond_floats": (_Z, []),

@@ -124,7 +124,9 @@ def ray_batch(height: int, width: int, fx: float, fy: float, cx: float, cy: floa
 
 
 # ---------------------------------------------------------------------------------------- K2
-def sample_coarse(n_rays: int, n_coarse: int, near: float, far: float, device, t_rand: Optional[torch.Tensor] = None):
+def sample_coarse(n_rays: int, n_coarse: int, near: float, far: float, device, t_rand: Optional[torch.Tensor] = None,
+                  lindisp: bool = False):
+    """T:56-76: stratified depths (n_rays, n_coarse); lindisp = the reference's linear-in-disparity spacing (T:65-66)."""
     t_rand = _c(t_rand)
     tv = linspace01(n_coarse, device)
     z = torch.empty((n_rays, n_coarse), dtype=torch.float32, device=device)
@@ -132,8 +134,8 @@ def sample_coarse(n_rays: int, n_coarse: int, near: float, far: float, device, t
         H.require_device(t_rand)
         assert tuple(t_rand.shape) == (n_rays, n_coarse)
     with torch.cuda.device(device):
-        H.check(H.lib().nf_sample_coarse(n_rays, n_coarse, float(np.float32(near)), float(np.float32(far)), H.ptr(tv),
-                                         H.ptr(t_rand), H.ptr(z), H.stream_ptr(device)), "nf_sample_coarse")
+        H.check(H.lib().nf_sample_coarse_ex(n_rays, n_coarse, float(np.float32(near)), float(np.float32(far)), H.ptr(tv),
+                                            H.ptr(t_rand), 1 if lindisp else 0, H.ptr(z), H.stream_ptr(device)), "nf_sample_coarse_ex")
     return z
 
 

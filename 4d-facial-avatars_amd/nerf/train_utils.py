@@ -64,7 +64,7 @@ class _RenderChunk(torch.autograd.Function):
         n_rays = ro.shape[0]
 
         lat_d = latent.detach().reshape(-1).contiguous()
-        z_c = ops.sample_coarse(n_rays, nc, near, far, dev, t_rand)
+        z_c = ops.sample_coarse(n_rays, nc, near, far, dev, t_rand, lindisp=cfg["lindisp"])
         raw_c, state_c = model_c.hip_forward(ro, rd, z_c, rd_view, expr, lat_d, near, far, need_grad)
         rgb_c, disp_c, acc_c, w_c = ops.volume_render_fwd(raw_c, z_c, rd, noise_c, bg, white)
         outs = [rgb_c, disp_c, acc_c]
@@ -139,8 +139,6 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     if not getattr(model_coarse, "fused_supported", lambda: False)():
         raise NotImplementedError(f"{type(model_coarse).__name__}: no fused HIP kernel for this model/geometry")
     m = getattr(options.nerf, mode)
-    if m.lindisp:
-        raise NotImplementedError("lindisp sampling is not used by any NeRFace config and is not built")
     if not ray_batch.is_cuda:
         raise RuntimeError("nerf (MI355X build): rays must be on a ROCm device; there is no CPU path")
     dev = ray_batch.device
@@ -174,6 +172,7 @@ def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mo
     expr = expressions.to(device=dev, dtype=torch.float32).reshape(-1).contiguous()
     need_grad = torch.is_grad_enabled() and (latent_code.requires_grad or any(p.requires_grad for p in params_c + params_f))
     cfg = dict(model_coarse=model_coarse, model_fine=model_fine if has_fine else None, near=near, far=far, num_coarse=nc,
+               lindisp=bool(m.lindisp),
                num_fine=nf if has_fine else 0, white_background=bool(m.white_background), need_grad=need_grad)
     lat = latent_code if latent_code.dtype == torch.float32 else latent_code.to(torch.float32)
     outs = _RenderChunk.apply(cfg, ro, rd, rd_view, bg, expr, lat, t_rand, noise_c, u, noise_f, len(params_c),

@@ -50,6 +50,10 @@ int nf_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy
  * passing the table keeps torch's own linspace rounding).  t_rand NULL => perturb off.  Bit-exact.    */
 int nf_sample_coarse(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
                      const float* t_rand, float* z, nf_stream_t stream);
+/* same with the reference's `lindisp` switch (T:65-66): lindisp != 0 spaces the depths linearly in disparity,
+ * z = 1 / (1/near (1 - t) + 1/far t).  Bit-exact.                                                       */
+int nf_sample_coarse_ex(int64_t n_rays, int n_coarse, float near_z, float far_z, const float* t_vals,
+                        const float* t_rand, int lindisp, float* z, nf_stream_t stream);
 
 /* ---- K3: positional encoder -- replaces positional_encoding (H:195-239) --------------------------- */
 /* x: (n_rows, dim) -> out: (n_rows, dim*(include_input + 2*n_freq)), layout [x | sin f0 | cos f0 | ..] */

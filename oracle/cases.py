@@ -35,6 +35,9 @@ CASES = {
     # "soft" family: SURVEY §8(d)'s density head (fc_alpha x40, bias 0.5) -- the tight per-stage tolerances apply to these
     "soft_eval_det_64_128": dict(frame=3, n_rays=64, n_coarse=64, n_fine=128, stochastic=False, noise_std=0.0, boost="survey"),
     "soft_train_rand_64_64": dict(frame=17, n_rays=48, n_coarse=64, n_fine=64, stochastic=True, noise_std=0.1, boost="survey"),
+    # the `lindisp` switch of the sampler (T:65-66: depths linear in disparity), perturbed, ragged sample counts
+    "soft_lindisp_rand_16_24": dict(frame=9, n_rays=20, n_coarse=16, n_fine=24, stochastic=True, noise_std=0.0, boost="survey",
+                                    lindisp=True),
 }
 
 
@@ -60,7 +63,7 @@ def build_case(name, dtype=torch.float32):
 def run_oracle(c, stages=None):
     return O.render_rays(c["p_coarse"], c["p_fine"], c["ro"], c["rd"], c["expr"], c["latent"], c["bg"],
                          O.NEAR, O.FAR, c["n_coarse"], c["n_fine"], t_rand=c["t_rand"], noise_c=c["noise_c"],
-                         u=c["u"], noise_f=c["noise_f"], stages=stages)
+                         u=c["u"], noise_f=c["noise_f"], stages=stages, lindisp=bool(c.get("lindisp", False)))
 
 
 def params_checksum(p) -> float:

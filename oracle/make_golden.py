@@ -21,8 +21,8 @@ from oracle import ref_import as RI                # noqa: E402
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
-def ref_options(ref, n_coarse, n_fine, perturb, noise_std):
-    mode = dict(num_coarse=n_coarse, num_fine=n_fine, chunksize=65536, perturb=perturb, lindisp=False,
+def ref_options(ref, n_coarse, n_fine, perturb, noise_std, lindisp=False):
+    mode = dict(num_coarse=n_coarse, num_fine=n_fine, chunksize=65536, perturb=perturb, lindisp=lindisp,
                 radiance_field_noise_std=noise_std, white_background=False, num_random_rays=2048)
     return ref.CfgNode(dict(nerf=dict(use_viewdirs=True, encode_position_fn="positional_encoding",
                                       encode_direction_fn="positional_encoding", train=dict(mode), validation=dict(mode)),
@@ -39,7 +39,7 @@ def ref_model(ref, params):
 
 def run_reference(ref, c, grad=False):
     mc, mf = ref_model(ref, c["p_coarse"]), ref_model(ref, c["p_fine"]) if c["n_fine"] > 0 else None
-    opt = ref_options(ref, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"])
+    opt = ref_options(ref, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"], bool(c.get("lindisp", False)))
     enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
     enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
     rands, randns = [], []

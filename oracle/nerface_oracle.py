@@ -226,11 +226,14 @@ def encode_points(ro, rd, z, near: float, far: float, rd_view=None) -> torch.Ten
 # --------------------------------------------------------------------------------------
 
 def coarse_z(n_rays: int, near: float, far: float, n_coarse: int, t_rand: Optional[torch.Tensor], dtype=torch.float32,
-             device=None):
+             device=None, lindisp: bool = False):
     t = torch.linspace(0.0, 1.0, n_coarse, dtype=dtype, device=device)
     nr = torch.full((n_rays, 1), near, dtype=dtype, device=device)
     fr = torch.full((n_rays, 1), far, dtype=dtype, device=device)
-    z = nr * (1.0 - t) + fr * t
+    if not lindisp:
+        z = nr * (1.0 - t) + fr * t
+    else:                                                       # T:65-66: linear in disparity
+        z = 1.0 / (1.0 / nr * (1.0 - t) + 1.0 / fr * t)
     if t_rand is not None:                                      # perturb=True (T:69-76)
         mids = 0.5 * (z[:, 1:] + z[:, :-1])
         upper = torch.cat((mids, z[:, -1:]), dim=-1)
@@ -307,7 +310,7 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
 
 def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: float, n_coarse: int, n_fine: int,
                 t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None, mlp=None,
-                point_chunk: int = 65536):
+                point_chunk: int = 65536, lindisp: bool = False):
     """Coarse pass -> hierarchical resample -> fine pass.  Returns the 7-tuple of T:162
     (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, weights_f[:, -1]).  Random tensors are injected
     (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates."""
@@ -321,7 +324,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
             return mlp_fn(p, x, e, l)
         return torch.cat([mlp_fn(p, x[k:k + point_chunk], e, l) for k in range(0, x.shape[0], point_chunk)], dim=0)
 
-    z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype, device=ro.device)
+    z = coarse_z(R, near, far, n_coarse, t_rand, dtype=ro.dtype, device=ro.device, lindisp=lindisp)
     raw = paper_mlp(p_coarse, encode_points(ro, rd, z, near, far, rd_view), expr, latent).reshape(R, n_coarse, 4).clone()
     st["raw_c_mlp"] = raw.clone()
     if bg is not None:

@@ -61,6 +61,12 @@ def test_sample_coarse_bit_exact(hip_lib, gpu, nc):
         assert torch.equal(z.cpu(), O.coarse_z(n, O.NEAR, O.FAR, nc, None))
         zr = ops.sample_coarse(n, nc, O.NEAR, O.FAR, gpu, t_rand.to(gpu))
         assert torch.equal(zr.cpu(), O.coarse_z(n, O.NEAR, O.FAR, nc, t_rand))
+        # lindisp (T:65-66): linear in disparity, same bit-exact contract; also with the tiny path's depth range
+        for near, far in ((O.NEAR, O.FAR), (2.0, 6.0)):
+            zl = ops.sample_coarse(n, nc, near, far, gpu, None, lindisp=True)
+            assert torch.equal(zl.cpu(), O.coarse_z(n, near, far, nc, None, lindisp=True))
+            zlr = ops.sample_coarse(n, nc, near, far, gpu, t_rand.to(gpu), lindisp=True)
+            assert torch.equal(zlr.cpu(), O.coarse_z(n, near, far, nc, t_rand, lindisp=True))
 
 
 def test_posenc(hip_lib, gpu):

@@ -6,8 +6,8 @@ import torch
 from oracle import nerface_oracle as O
 
 
-def make_options(nerf, n_coarse, n_fine, perturb, noise_std, chunksize=65536, white=False):
-    mode = dict(num_coarse=n_coarse, num_fine=n_fine, chunksize=chunksize, perturb=perturb, lindisp=False,
+def make_options(nerf, n_coarse, n_fine, perturb, noise_std, chunksize=65536, white=False, lindisp=False):
+    mode = dict(num_coarse=n_coarse, num_fine=n_fine, chunksize=chunksize, perturb=perturb, lindisp=lindisp,
                 radiance_field_noise_std=noise_std, white_background=white, num_random_rays=2048)
     return nerf.CfgNode(dict(nerf=dict(use_viewdirs=True, encode_position_fn="positional_encoding",
                                        encode_direction_fn="positional_encoding", train=dict(mode), validation=dict(mode)),
@@ -65,7 +65,8 @@ def run_product(nerf, c, device, mode="train", grad=False, chunksize=65536):
     """run_one_iter_of_nerf of the product package on case `c` (see oracle/cases.py)."""
     mc = make_model(nerf, c["p_coarse"], device)
     mf = make_model(nerf, c["p_fine"], device) if c["n_fine"] > 0 else None
-    opt = make_options(nerf, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"], chunksize)
+    opt = make_options(nerf, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"], chunksize,
+                       lindisp=bool(c.get("lindisp", False)))
     ex, ed = encoders(nerf)
     latent = c["latent"].clone().to(device).requires_grad_(grad)
     rands, randns = case_random_lists(c)
