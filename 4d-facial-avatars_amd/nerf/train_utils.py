@@ -60,6 +60,7 @@ class _RenderChunk(torch.autograd.Function):
         near, far, nc, nf = cfg["near"], cfg["far"], cfg["num_coarse"], cfg["num_fine"]
         white = cfg["white_background"]
         need_grad = cfg["need_grad"]
+        ctx.set_materialize_grads(False)       # the five non-differentiable outputs would each cost a zero-fill kernel per backward
         dev = ro.device
         n_rays = ro.shape[0]
 
@@ -96,13 +97,12 @@ class _RenderChunk(torch.autograd.Function):
         model_c, model_f = cfg["model_coarse"], cfg["model_fine"]
         white = cfg["white_background"]
         d_rgb_c = grads[0]
-        g_latent = torch.zeros(32, dtype=torch.float32, device=rd.device)
+        g_latent = None
         grads_c = [None] * ctx.n_params_c
         grads_f = []
         if d_rgb_c is not None:
             d_raw_c = ops.volume_render_bwd(raw_c, z_c, rd, noise_c, bg, d_rgb_c, white)
-            grads_c, gl = model_c.hip_backward(ctx.state_c, z_c, d_raw_c)
-            g_latent = g_latent + gl
+            grads_c, g_latent = model_c.hip_backward(ctx.state_c, z_c, d_raw_c)
         ctx.state_c = None
         if ctx.has_fine:
             z_f, raw_f, state_f = ctx.fine
@@ -111,9 +111,9 @@ class _RenderChunk(torch.autograd.Function):
             if d_rgb_f is not None:
                 d_raw_f = ops.volume_render_bwd(raw_f, z_f, rd, noise_f, bg, d_rgb_f, white)
                 grads_f, gl = model_f.hip_backward(state_f, z_f, d_raw_f)
-                g_latent = g_latent + gl
+                g_latent = gl if g_latent is None else g_latent + gl
             ctx.fine = None
-        g_latent = g_latent.reshape(latent.shape) if ctx.needs_input_grad[6] else None
+        g_latent = g_latent.reshape(latent.shape) if (ctx.needs_input_grad[6] and g_latent is not None) else None
         # inputs: cfg, ro, rd, rd_view, bg, expr, latent, t_rand, noise_c, u, noise_f, n_params_c, *params
         return (None, None, None, None, None, None, g_latent, None, None, None, None, None, *grads_c, *grads_f)
 
@@ -129,30 +129,41 @@ def _check_encoders(encode_position_fn, encode_direction_fn):
             "for positions and get_embedding_function(4, include_input=False) for directions (log sampling)")
 
 
-def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mode="train", encode_position_fn=None,
-                                encode_direction_fn=None, expressions=None, background_prior=None, latent_code=None,
-                                ray_dirs_fake=None):
-    """T:36-162 for one ray chunk: ray_batch (n, 8) = [ro, rd, near, far]; returns the 7-tuple of T:162."""
+def _check_chunk_args(model_coarse, encode_position_fn, encode_direction_fn, expressions, latent_code, rays):
     _check_encoders(encode_position_fn, encode_direction_fn)
     if expressions is None or latent_code is None:
         raise NotImplementedError("the NeRFace path needs `expressions` and `latent_code` (unconditioned NeRF is out of scope)")
     if not getattr(model_coarse, "fused_supported", lambda: False)():
         raise NotImplementedError(f"{type(model_coarse).__name__}: no fused HIP kernel for this model/geometry")
-    m = getattr(options.nerf, mode)
-    if not ray_batch.is_cuda:
+    if not rays.is_cuda:
         raise RuntimeError("nerf (MI355X build): rays must be on a ROCm device; there is no CPU path")
-    dev = ray_batch.device
+
+
+def predict_and_render_radiance(ray_batch, model_coarse, model_fine, options, mode="train", encode_position_fn=None,
+                                encode_direction_fn=None, expressions=None, background_prior=None, latent_code=None,
+                                ray_dirs_fake=None):
+    """T:36-162 for one ray chunk: ray_batch (n, 8) = [ro, rd, near, far]; returns the 7-tuple of T:162."""
+    _check_chunk_args(model_coarse, encode_position_fn, encode_direction_fn, expressions, latent_code, ray_batch)
     n_rays = ray_batch.shape[0]
-    nc, nf = int(m.num_coarse), int(m.num_fine)
     rb = ray_batch.to(torch.float32)
     ro = rb[:, 0:3].contiguous()
     rd = rb[:, 3:6].contiguous()
-    near, far = float(options.dataset.near), float(options.dataset.far)
     # Quirk Q7 (T:81-82): on the ablation path the *encoded* direction comes from chunk 0 of the fake rays
     rd_view = None
     if ray_dirs_fake:
         rd_view = ray_dirs_fake[0][:n_rays, 3:6].to(torch.float32).contiguous()
         ray_batch[..., 3:6] = ray_dirs_fake[0][..., 3:6]           # same in-place side effect as the reference
+    return _render_rays(ro, rd, rd_view, model_coarse, model_fine, options, mode, expressions, background_prior, latent_code)
+
+
+def _render_rays(ro, rd, rd_view, model_coarse, model_fine, options, mode, expressions, background_prior, latent_code):
+    """The body of predict_and_render_radiance on (n, 3) origins / directions: run_one_iter_of_nerf calls it with row views of
+    its inputs, without the (n, 8) ray_batch detour of T:206-212 (two fills, two multiplies, a cat and two slice copies per call)."""
+    m = getattr(options.nerf, mode)
+    dev = ro.device
+    n_rays = ro.shape[0]
+    nc, nf = int(m.num_coarse), int(m.num_fine)
+    near, far = float(options.dataset.near), float(options.dataset.far)
     has_fine = nf > 0 and model_fine is not None
     noise_std = float(m.radiance_field_noise_std)
     # ---- random draws, in the reference's order and shapes (T:75, V:41-50, H:363-367) --------------
@@ -198,25 +209,37 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
         restore_shapes += [ray_directions.shape[:-1]]
     ro = ray_origins.reshape((-1, 3))
     rd = ray_directions.reshape((-1, 3))
-    near = options.dataset.near * torch.ones_like(rd[..., :1])
-    far = options.dataset.far * torch.ones_like(rd[..., :1])
-    rays = torch.cat((ro, rd, near, far), dim=-1)                              # (R, 8), T:206-212
     chunksize = getattr(options.nerf, mode).chunksize
-    batches = get_minibatches(rays, chunksize=chunksize)
-    batches_ablation = None
+    bg_chunks = get_minibatches(background_prior, chunksize=chunksize) if background_prior is not None else None
     if is_rad:
+        # ablation call pattern (EV:449-467): the reference's own (R, 8) ray batches, chunked, with the in-place side effect of
+        # T:81-82 on them
+        near = options.dataset.near * torch.ones_like(rd[..., :1])
+        far = options.dataset.far * torch.ones_like(rd[..., :1])
+        rays = torch.cat((ro, rd, near, far), dim=-1)                              # (R, 8), T:206-212
+        batches = get_minibatches(rays, chunksize=chunksize)
         rays_ablation = torch.cat((ro, ray_directions_ablation.reshape((-1, 3)), near, far), dim=-1)
         batches_ablation = get_minibatches(rays_ablation, chunksize=chunksize)
-    bg_chunks = get_minibatches(background_prior, chunksize=chunksize) if background_prior is not None else None
-    pred = [
-        predict_and_render_radiance(batch, model_coarse, model_fine, options, mode, encode_position_fn=encode_position_fn,
-                                    encode_direction_fn=encode_direction_fn, expressions=expressions,
-                                    background_prior=bg_chunks[i] if bg_chunks is not None else None,
-                                    latent_code=latent_code, ray_dirs_fake=batches_ablation)
-        for i, batch in enumerate(batches)
-    ]
+        pred = [
+            predict_and_render_radiance(batch, model_coarse, model_fine, options, mode, encode_position_fn=encode_position_fn,
+                                        encode_direction_fn=encode_direction_fn, expressions=expressions,
+                                        background_prior=bg_chunks[i] if bg_chunks is not None else None,
+                                        latent_code=latent_code, ray_dirs_fake=batches_ablation)
+            for i, batch in enumerate(batches)
+        ]
+    else:
+        # same chunks (T:213 get_minibatches over the rays), taken as row views of the caller's origins / directions: near and far
+        # are the two scalars of the config, so the (R, 8) concatenation of T:206-212 carries nothing the kernels need
+        _check_chunk_args(model_coarse, encode_position_fn, encode_direction_fn, expressions, latent_code, ro)
+        ro32 = ro if (ro.dtype == torch.float32 and ro.is_contiguous()) else ro.to(torch.float32).contiguous()
+        rd32 = rd if (rd.dtype == torch.float32 and rd.is_contiguous()) else rd.to(torch.float32).contiguous()
+        pred = [
+            _render_rays(ro32[i0:i0 + chunksize], rd32[i0:i0 + chunksize], None, model_coarse, model_fine, options, mode, expressions,
+                         bg_chunks[k] if bg_chunks is not None else None, latent_code)
+            for k, i0 in enumerate(range(0, ro32.shape[0], chunksize))
+        ]
     synthesized = list(zip(*pred))
-    synthesized = [torch.cat(img, dim=0) if img[0] is not None else None for img in synthesized]
+    synthesized = [(img[0] if len(img) == 1 else torch.cat(img, dim=0)) if img[0] is not None else None for img in synthesized]
     if ops.get_mlp_precision() == "f16x3" and not torch.is_grad_enabled():
         ops.check_f16_range(model_coarse, model_fine)              # once per call (per frame in validation mode), after all chunks
     if mode == "validation":
