@@ -143,83 +143,52 @@ static void nfb_build_dw_jobs_lcode(NfbDwJob* jobs) {
 
 static void nfb_build_dw_jobs(NfbDwJob* jobs) {
     using namespace nfl;
-    int nj = 0;
-    int first_tile[4];
     // dz section -> the chain's layer index (slot of max |dz|)
-    auto slot_of = [](int z) {
-        const int order[10] = {Z_D2, Z_D1, Z_D0, Z_FEAT, Z_L5, Z_L4, Z_L3, Z_L2, Z_L1, Z_L0};
-        for (int i = 0; i < 10; ++i)
-            if (order[i] == z) return i;
-        return -1;
-    };
-    auto new_job = [&]() -> NfbDwJob& {
-        NfbDwJob& j = jobs[nj++];
-        j.nseg = j.ntile = 0;
-        for (auto& s : j.seg) s = NfbDwSeg{0, 0, 0, -1};
-        for (auto& t : j.tile) t = NfbDwTile{0, 0, -1};
-        for (auto& p : j.prod) p = NfbDwProd{0, 0, 0, 0, 0, 0, 0, 0};   // idle wave: multiplies tiles 0, 1 and stores nothing
-        return j;
-    };
-    // segment + its tiles; cs >= 0: slab offset of the column sums of the section
-    auto add_seg = [&](NfbDwJob& j, int kind, int sec, int width, int cs) {
-        j.seg[j.nseg] = NfbDwSeg{kind, sec, width, kind == 2 ? -1 : (kind == 1 ? 10 : slot_of(sec))};
-        first_tile[j.nseg] = j.ntile;
-        for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
-        return j.nseg++;
-    };
-    // rows [a0, a0 + a_valid) of segment sa  x  columns [b0, b0 + b_valid) of segment sb   (a0, b0 multiples of 32)
-    auto prod = [&](int sa, int a0, int a_valid, int sb, int b0, int b_valid, int out_off, int ldo) {
-        return NfbDwProd{(a_valid + 31) / 32, (b_valid + 31) / 32, first_tile[sa] + a0 / 32, first_tile[sb] + b0 / 32,
-                         a_valid, b_valid, out_off, ldo};
-    };
-    // 256 x 256 layers: 4 x 4 blocks of 64 x 64
-    auto layer256 = [&](int zsec, int bsec, int gout, int cs) {
-        NfbDwJob& j = new_job();
-        const int sa = add_seg(j, 0, zsec, 256, cs), sb = add_seg(j, 2, bsec, 256, -1);
-        for (int w = 0; w < 16; ++w) {
-            const int ag = w >> 2, bg = w & 3;
-            j.prod[w] = prod(sa, 64 * ag, 64, sb, 64 * bg, 64, gout + 64 * ag * 256 + 64 * bg, 256);
-        }
-    };
-    layer256(Z_L1, S_H0, G_L1, CS_L0 + 256);
-    layer256(Z_L2, S_H1, G_L2, CS_L0 + 512);
-    layer256(Z_L3, S_H2, G_L3B, -1);
-    layer256(Z_L4, S_H3, G_L4, CS_L0 + 1024);
-    layer256(Z_L5, S_H4, G_L5, CS_L0 + 1280);
-    layer256(Z_FEAT, S_H5, G_FEAT, CS_L0 + 1536);
+    NfbDwBuilder b{jobs, [](int z) {
+                       const int order[10] = {Z_D2, Z_D1, Z_D0, Z_FEAT, Z_L5, Z_L4, Z_L3, Z_L2, Z_L1, Z_L0};
+                       for (int i = 0; i < 10; ++i)
+                           if (order[i] == z) return i;
+                       return -1;
+                   }};
+    b.layer256(Z_L1, S_H0, G_L1, CS_L0 + 256);
+    b.layer256(Z_L2, S_H1, G_L2, CS_L0 + 512);
+    b.layer256(Z_L3, S_H2, G_L3B, -1);
+    b.layer256(Z_L4, S_H3, G_L4, CS_L0 + 1024);
+    b.layer256(Z_L5, S_H4, G_L5, CS_L0 + 1280);
+    b.layer256(Z_FEAT, S_H5, G_FEAT, CS_L0 + 1536);
     for (int q = 0; q < 2; ++q) {   // the two products against the positional encoding: dZ_L0 x PE, dZ_L3 x PE
-        NfbDwJob& j = new_job();
-        const int sz = add_seg(j, 0, q ? Z_L3 : Z_L0, 256, q ? CS_L0 + 768 : CS_L0), sp = add_seg(j, 2, S_PE, 64, -1);
-        for (int w = 0; w < 8; ++w) j.prod[w] = prod(sz, 32 * w, 32, sp, 0, 64, (q ? G_L3A : G_L0) + 32 * w * 64, 64);
+        NfbDwJob& j = b.new_job();
+        const int sz = b.add_seg(j, 0, q ? Z_L3 : Z_L0, 256, q ? CS_L0 + 768 : CS_L0), sp = b.add_seg(j, 2, S_PE, 64, -1);
+        for (int w = 0; w < 8; ++w) j.prod[w] = b.prod(sz, 32 * w, 32, sp, 0, 64, (q ? G_L3A : G_L0) + 32 * w * 64, 64);
     }
     {   // (dZ_D0 | d_raw) x feat
-        NfbDwJob& j = new_job();
-        const int sz = add_seg(j, 0, Z_D0, 128, CS_D0), sf = add_seg(j, 2, S_FEAT, 256, -1), sr = add_seg(j, 1, 0, 4, -1);
+        NfbDwJob& j = b.new_job();
+        const int sz = b.add_seg(j, 0, Z_D0, 128, CS_D0), sf = b.add_seg(j, 2, S_FEAT, 256, -1), sr = b.add_seg(j, 1, 0, 4, -1);
         for (int w = 0; w < 8; ++w) {
             const int ag = w >> 2, bg = w & 3;
-            j.prod[w] = prod(sz, 64 * ag, 64, sf, 64 * bg, 64, G_D0A + 64 * ag * 256 + 64 * bg, 256);
+            j.prod[w] = b.prod(sz, 64 * ag, 64, sf, 64 * bg, 64, G_D0A + 64 * ag * 256 + 64 * bg, 256);
         }
         for (int bg = 0; bg < 4; ++bg)     // row 3 (d sigma) = fc_alpha.weight gradient
-            j.prod[8 + bg] = prod(sr, 0, 4, sf, 64 * bg, 64, G_ALPHA + 64 * bg, 256);
+            j.prod[8 + bg] = b.prod(sr, 0, 4, sf, 64 * bg, 64, G_ALPHA + 64 * bg, 256);
     }
     {   // dZ_D1 x d0 and dZ_D2 x d1
-        NfbDwJob& j = new_job();
-        const int z1 = add_seg(j, 0, Z_D1, 128, CS_D0 + 128), a0 = add_seg(j, 2, S_D0, 128, -1);
-        const int z2 = add_seg(j, 0, Z_D2, 128, CS_D0 + 256), a1 = add_seg(j, 2, S_D1, 128, -1);
+        NfbDwJob& j = b.new_job();
+        const int z1 = b.add_seg(j, 0, Z_D1, 128, CS_D0 + 128), a0 = b.add_seg(j, 2, S_D0, 128, -1);
+        const int z2 = b.add_seg(j, 0, Z_D2, 128, CS_D0 + 256), a1 = b.add_seg(j, 2, S_D1, 128, -1);
         for (int w = 0; w < 4; ++w) {
             const int ag = w >> 1, bg = w & 1;
-            j.prod[w] = prod(z1, 64 * ag, 64, a0, 64 * bg, 64, G_D1 + 64 * ag * 128 + 64 * bg, 128);
-            j.prod[4 + w] = prod(z2, 64 * ag, 64, a1, 64 * bg, 64, G_D2 + 64 * ag * 128 + 64 * bg, 128);
+            j.prod[w] = b.prod(z1, 64 * ag, 64, a0, 64 * bg, 64, G_D1 + 64 * ag * 128 + 64 * bg, 128);
+            j.prod[4 + w] = b.prod(z2, 64 * ag, 64, a1, 64 * bg, 64, G_D2 + 64 * ag * 128 + 64 * bg, 128);
         }
     }
     {   // dZ_D0 x dir features, d_raw x d2 (fc_rgb.weight; the 4 output-bias gradients are the column sums of d_raw)
-        NfbDwJob& j = new_job();
-        const int sz = add_seg(j, 0, Z_D0, 128, -1), sd = add_seg(j, 2, S_DIRF, 16, -1), sr = add_seg(j, 1, 0, 4, CS_RGB);
-        const int s2 = add_seg(j, 2, S_D2, 128, -1);
-        for (int ag = 0; ag < 2; ++ag) j.prod[ag] = prod(sz, 64 * ag, 64, sd, 0, 16, G_D0B + 64 * ag * 16, 16);
-        for (int bg = 0; bg < 2; ++bg) j.prod[2 + bg] = prod(sr, 0, 4, s2, 64 * bg, 64, G_RGB + 64 * bg, 128);
+        NfbDwJob& j = b.new_job();
+        const int sz = b.add_seg(j, 0, Z_D0, 128, -1), sd = b.add_seg(j, 2, S_DIRF, 16, -1), sr = b.add_seg(j, 1, 0, 4, CS_RGB);
+        const int s2 = b.add_seg(j, 2, S_D2, 128, -1);
+        for (int ag = 0; ag < 2; ++ag) j.prod[ag] = b.prod(sz, 64 * ag, 64, sd, 0, 16, G_D0B + 64 * ag * 16, 16);
+        for (int bg = 0; bg < 2; ++bg) j.prod[2 + bg] = b.prod(sr, 0, 4, s2, 64 * bg, 64, G_RGB + 64 * bg, 128);
     }
-    // nj == NFB_DW_JOBS by construction
+    // b.nj == NFB_DW_JOBS by construction
 }
 
 __device__ __forceinline__ void nfb_dw_split(const float (&x)[8], bf16x8& hi, bf16x8& lo) {

@@ -38,12 +38,12 @@ extern "C" int nf_ray_bundle(int height, int width, float fx, float fy, float cx
     NF_RETURN_LAUNCH();
 }
 
-// K1 for a training batch: the rays of `n` selected pixels only (sel[i] = {row, col}, int64 as torch.multinomial / indexing
-// hands them over), with the same arithmetic as k_ray_bundle -- bit-identical to gathering from the full bundle -- plus the
+// K1 for a training batch: the rays of `n` selected pixels only (sel[i] = {row, col}, int64 as indexing hands them over, or flat
+// pixel indices row * W + col as K0 / torch.multinomial return them), with the same arithmetic as k_ray_bundle -- bit-identical to gathering from the full bundle -- plus the
 // gathers of the target pixels (image (H, W, C)) and of the background prior (H, W, 3) in the same pass.  Replaces the
 // reference's full-frame get_ray_bundle + four index gathers per iteration (train_transformed_rays.py:302, 325-330).
 __global__ void __launch_bounds__(256) k_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h,
-                                                   const float* __restrict__ c2w, int rs, const int64_t* __restrict__ sel, int64_t n,
+                                                   const float* __restrict__ c2w, int rs, const int64_t* __restrict__ sel, int flat, int64_t n,
                                                    const float* __restrict__ image, int channels, const float* __restrict__ bg,
                                                    float* __restrict__ ro, float* __restrict__ rd, float* __restrict__ target,
                                                    float* __restrict__ bg_out, int* __restrict__ bad) {
@@ -51,7 +51,9 @@ __global__ void __launch_bounds__(256) k_ray_batch(int height, int width, float 
     const float r10 = c2w[rs + 0], r11 = c2w[rs + 1], r12 = c2w[rs + 2], t1 = c2w[rs + 3];
     const float r20 = c2w[2 * rs + 0], r21 = c2w[2 * rs + 1], r22 = c2w[2 * rs + 2], t2 = c2w[2 * rs + 3];
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        int64_t h = sel[2 * i], w = sel[2 * i + 1];
+        int64_t h, w;
+        if (flat) { const int64_t px = sel[i]; h = px >= 0 ? px / width : -1; w = px - h * width; }   // flat pixel index (what K0 returns)
+        else { h = sel[2 * i]; w = sel[2 * i + 1]; }
         if (h < 0 || h >= height || w < 0 || w >= width) {            // reported to the host; the lane writes pixel (0, 0)
             atomicOr(bad, 1);
             h = 0; w = 0;
@@ -74,15 +76,15 @@ __global__ void __launch_bounds__(256) k_ray_batch(int height, int width, float 
 }
 
 extern "C" int nf_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h, const float* c2w, int c2w_row_stride,
-                            const int64_t* sel, int64_t n, const float* image, int channels, const float* bg, float* ro, float* rd,
-                            float* target, float* bg_out, int* bad_flag, nf_stream_t stream) {
+                            const int64_t* sel, int sel_is_flat, int64_t n, const float* image, int channels, const float* bg, float* ro,
+                            float* rd, float* target, float* bg_out, int* bad_flag, nf_stream_t stream) {
     if (n == 0) return 0;
     if (height <= 0 || width <= 0 || n < 0 || !c2w || !sel || !ro || !rd || !bad_flag || c2w_row_stride < 4 ||
         (target && (!image || channels <= 0)) || (bg_out && !bg))
         return NF_EINVAL;
     const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
     hipLaunchKernelGGL(k_ray_batch, dim3(grid), dim3(256), 0, nf_s(stream), height, width, fx, fy, cx_w, cy_h, c2w, c2w_row_stride,
-                       sel, n, image, channels, bg, ro, rd, target, bg_out, bad_flag);
+                       sel, sel_is_flat ? 1 : 0, n, image, channels, bg, ro, rd, target, bg_out, bad_flag);
     NF_RETURN_LAUNCH();
 }
 

@@ -5,8 +5,8 @@ per rank per step and one flat RCCL gradient all-reduce.
 
 Same CLI, YAML schema and checkpoint dictionary as the reference (`iter, model_coarse_state_dict, model_fine_state_dict,
 optimizer_state_dict, loss, psnr, background, latent_codes`; two optimizer param groups).  Differences, all outside the
-hot path: ray selection (importance map, p = 0.9 inside the bbox, TR:230-239) draws on the device with
-torch.multinomial instead of np.random.choice; no TensorBoard; rank 0 writes checkpoints; on resume the latent codes and
+hot path: ray selection (importance map, p = 0.9 inside the bbox, TR:230-239) draws on the device (nerf.choose_rays: a HIP
+radix select over exponential keys, torch's generator) instead of np.random.choice on the host; no TensorBoard; rank 0 writes checkpoints; on resume the latent codes and
 background are restored *into* the tensors the optimizer already owns (the reference re-wraps them and the optimizer
 keeps stepping the stale ones).
 """
@@ -77,8 +77,7 @@ def main(argv=None):
     # from here on every rank draws its OWN rays and noise: the shared seed above served the identical initialisation only
     torch.manual_seed(D.rank_seed(seed))
     reducer = D.GradientAllReducer(trainable)
-    maps = [torch.from_numpy(m).to(dev) for m in importance_maps(bboxs[i_train].numpy(), H, W)]
-    coords = torch.stack(nerf.meshgrid_xy(torch.arange(H, device=dev), torch.arange(W, device=dev)), dim=-1).reshape(-1, 2)
+    maps = [torch.from_numpy(m).to(device=dev, dtype=torch.float32) for m in importance_maps(bboxs[i_train].numpy(), H, W)]
     logdir = os.path.join(cfg.experiment.logdir, cfg.experiment.id)
     if rank == 0:
         os.makedirs(logdir, exist_ok=True)
@@ -95,9 +94,9 @@ def main(argv=None):
         img_idx = int(i_train[k])
         target_img, pose, expr = stager.fetch(img_idx)
         latent = latent_codes[k]
-        sel = coords[torch.multinomial(maps[k], n_rays, replacement=False)]
+        sel = nerf.choose_rays(maps[k], n_rays)               # TR:320-322 on the device: n distinct pixels, p = the importance map
         if first_draw is None:
-            first_draw = (img_idx, sel[:8].clone())
+            first_draw = (img_idx, sel[:16].clone())
         # rays, target pixels and background prior of the selected pixels only, one kernel (TR:302 builds the full 512 x 512
         # bundle every iteration and gathers four times, TR:325-330)
         ro, rd, target, bg = nerf.get_ray_batch(H, W, intrinsics, pose, sel, target_img, background)

@@ -12,7 +12,7 @@ from .load_llff import load_llff_data
 from . import models
 from .models import *  # noqa: F401,F403
 from .nerf_helpers import *  # noqa: F401,F403
-from .nerf_helpers import (cumprod_exclusive, dump_rays, get_embedding_function, get_minibatches, get_ray_batch, get_ray_bundle, img2mse,
+from .nerf_helpers import (choose_rays, cumprod_exclusive, dump_rays, get_embedding_function, get_minibatches, get_ray_batch, get_ray_bundle, img2mse,
                            meshgrid_xy, mse2psnr, ndc_rays, positional_encoding, sample_pdf, sample_pdf_2)
 from .train_utils import *  # noqa: F401,F403
 from .train_utils import GaussianSmoothing, predict_and_render_radiance, run_network, run_one_iter_of_nerf

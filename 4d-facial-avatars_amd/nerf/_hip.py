@@ -24,7 +24,9 @@ _PROTOTYPES = {
     "nf_error_string": (C.c_char_p, [_I]),
     "nf_build_info": (C.c_char_p, []),
     "nf_ray_bundle": (C.c_int, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _P, _P]),
-    "nf_ray_batch": (C.c_int, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "nf_weighted_choice_workspace_bytes": (_Z, []),
+    "nf_weighted_choice": (C.c_int, [_P, _P, _L, _I, _P, _P, _Z, _P]),
+    "nf_ray_batch": (C.c_int, [_I, _I, _F, _F, _F, _F, _P, _I, _P, _I, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P]),
     "nf_sample_coarse": (C.c_int, [_L, _I, _F, _F, _P, _P, _P, _P]),
     "nf_sample_coarse_ex": (C.c_int, [_L, _I, _F, _F, _P, _P, _I, _P, _P]),
     "nf_posenc": (C.c_int, [_P, _L, _I, _I, _I, _P, _P]),

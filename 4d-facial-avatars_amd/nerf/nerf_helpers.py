@@ -62,10 +62,18 @@ def get_ray_bundle(height: int, width: int, intrinsics, tform_cam2world: torch.T
     return ops.ray_bundle(int(height), int(width), fx, fy, cx, cy, tform_cam2world)
 
 
+def choose_rays(probs: torch.Tensor, n: int, check: bool = False) -> torch.Tensor:
+    """The trainer's ray selection (TR:320-322: np.random.choice(H * W, size=n, replace=False, p=probs) on the host) on the device:
+    n distinct pixel indices drawn without replacement with probabilities proportional to `probs` (nf_weighted_choice).  Not in the
+    reference (the launchers' replacement); the random numbers come from torch's device generator."""
+    return ops.weighted_choice(probs, int(n), check=check)
+
+
 def get_ray_batch(height: int, width: int, intrinsics, tform_cam2world: torch.Tensor, select_inds: torch.Tensor, target_img=None,
                   background=None, check: bool = False):
     """Training-batch form of get_ray_bundle (not in the reference: the launcher's replacement for TR:302 + TR:325-330):
-    rays, target pixels and background prior of the pixels select_inds (n, 2) = {row, col} only, one kernel (nf_ray_batch).
+    rays, target pixels and background prior of the pixels select_inds -- (n, 2) = {row, col}, or (n,) flat indices as choose_rays
+    returns them -- only, one kernel (nf_ray_batch).
     Rays are bit-identical to get_ray_bundle(...)[select_inds[:, 0], select_inds[:, 1]]."""
     fx, fy, cx, cy = _intrinsics4(intrinsics)
     return ops.ray_batch(int(height), int(width), fx, fy, cx, cy, tform_cam2world, select_inds, target_img, background, check)

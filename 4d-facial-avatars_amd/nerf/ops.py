@@ -89,14 +89,46 @@ def ray_bundle(height: int, width: int, fx: float, fy: float, cx: float, cy: flo
     return ro, rd
 
 
+# ---------------------------------------------------------------------------------------- K0
+def weighted_choice(weights: torch.Tensor, n: int, u: Optional[torch.Tensor] = None, check: bool = False) -> torch.Tensor:
+    """np.random.choice(len(weights), size=n, replace=False, p=weights / weights.sum()) on the device (TR:320-322): n distinct int64
+    indices in ascending order (a seed reproduces the batch element for element).  u: the uniform numbers to use (len(weights), in [0, 1)); default torch.rand on the device, i.e.
+    torch's generator and seeds.  check=True reads the "fewer than n positive weights" flag back (host sync) and raises ValueError
+    like numpy does."""
+    w = _c(weights.reshape(-1))
+    dev = H.require_device(w)
+    n_items = int(w.numel())
+    if not 0 <= n <= n_items:
+        raise ValueError("Cannot take a larger sample than population when replace is False")
+    if u is None:
+        u = torch.rand(n_items, dtype=torch.float32, device=dev)
+    u = _c(u.reshape(-1))
+    H.require_device(u)
+    if u.numel() != n_items:
+        raise ValueError("u must hold one uniform number per weight")
+    lib = H.lib()
+    ws_bytes = int(lib.nf_weighted_choice_workspace_bytes())
+    ws = torch.empty(ws_bytes // 4, dtype=torch.int32, device=dev)
+    idx = torch.empty(n, dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        H.check(lib.nf_weighted_choice(H.ptr(w), H.ptr(u), n_items, int(n), H.ptr(idx), H.ptr(ws), ws_bytes, H.stream_ptr(dev)),
+                "nf_weighted_choice")
+    if check and n > 0 and int(ws[5].item()):
+        raise ValueError("Fewer non-zero entries in p than size")
+    if n > 8192:                                          # the in-kernel sort covers the trainer's batch sizes
+        idx = torch.sort(idx)[0]
+    return idx
+
+
 def ray_batch(height: int, width: int, fx: float, fy: float, cx: float, cy: float, c2w: torch.Tensor, sel: torch.Tensor,
               image: Optional[torch.Tensor] = None, background: Optional[torch.Tensor] = None, check: bool = False):
-    """Rays of the selected pixels only (sel (n, 2) int64 {row, col}) -- bit-identical to get_ray_bundle(...)[sel[:, 0], sel[:, 1]]
+    """Rays of the selected pixels only (sel (n, 2) int64 {row, col}, or (n,) flat pixel indices row * W + col) -- bit-identical to
+    get_ray_bundle(...)[sel[:, 0], sel[:, 1]]
     -- plus the target pixels of `image` (H, W, C) and the background prior (H, W, 3) at the same pixels, in one launch
     (TR:302, 325-330).  Returns (ro, rd, target | None, bg | None).  check=True reads the out-of-range flag back (host sync)."""
     c2w = c2w if (c2w.dtype == torch.float32 and c2w.stride(-1) == 1) else c2w.to(torch.float32).contiguous()
-    if sel.dtype != torch.int64 or sel.dim() != 2 or sel.shape[1] != 2:
-        raise ValueError("sel must be an (n, 2) int64 tensor of {row, col}")
+    if sel.dtype != torch.int64 or not (sel.dim() == 1 or (sel.dim() == 2 and sel.shape[1] == 2)):
+        raise ValueError("sel must be an (n, 2) int64 tensor of {row, col} or an (n,) int64 tensor of flat pixel indices")
     sel, image, background = sel.contiguous(), _c(image), _c(background)
     dev = H.require_device(c2w, image, background)
     if sel.device != dev:
@@ -116,7 +148,8 @@ def ray_batch(height: int, width: int, fx: float, fy: float, cx: float, cy: floa
     cy_h = float(np.float32(np.float64(height) * np.float64(cy)))
     with torch.cuda.device(dev):
         H.check(H.lib().nf_ray_batch(height, width, float(np.float32(fx)), float(np.float32(fy)), cx_w, cy_h, H.ptr(c2w),
-                                     int(c2w.stride(0)), H.ptr(sel), n, H.ptr(image), ch, H.ptr(background), H.ptr(ro), H.ptr(rd),
+                                     int(c2w.stride(0)), H.ptr(sel), 1 if sel.dim() == 1 else 0, n, H.ptr(image), ch, H.ptr(background),
+                                     H.ptr(ro), H.ptr(rd),
                                      H.ptr(target), H.ptr(bg), H.ptr(flag), H.stream_ptr(dev)), "nf_ray_batch")
     if check and int(flag.item()):
         raise IndexError("ray_batch: a selected pixel lies outside the image")

@@ -243,15 +243,18 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     background = torch.rand((H, W, 3), generator=g).to(dev)
     target = torch.rand((H, W, 3), generator=g).to(dev)
     torch.manual_seed(D.rank_seed(1234))
+    importance = torch.full((H, W), 0.1, device=dev)                   # the trainer's importance map (TR:230-239) for a centred face box
+    importance[H // 5: 4 * H // 5, W // 4: 3 * W // 4] = 0.9
+    importance = (importance / importance.sum()).reshape(-1)
     n_it = args.steps + args.warmup
     frame_ids = torch.randint(0, n_train, (n_it,)).tolist()
     poses = [frame_pose(f).to(dev) for f in frame_ids]
     exprs = [(0.5 * torch.randn(76)).to(dev) for _ in frame_ids]
 
     def step(i):
-        idx = torch.randperm(H * W, device=dev)[:n_rays]
-        sel = torch.stack((idx // W, idx % W), dim=-1)
-        # rays + target pixels + background prior of the selected pixels in one kernel (the launcher's form of TR:302, 325-330)
+        # TR:320-322 on the device: 2048 distinct pixels, importance-sampled (p = 0.9 inside the face box, TR:230-239), then rays +
+        # target pixels + background prior of the selected pixels in one kernel (the launcher's form of TR:302, 325-330)
+        sel = nerf.choose_rays(importance, n_rays)
         ro, rd, tgt, bg = nerf.get_ray_batch(H, W, INTRINSICS, poses[i], sel, target, background)
         latent = latent_codes[frame_ids[i]]
         out = nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro, rd, opt,

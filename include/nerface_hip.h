@@ -38,12 +38,23 @@ int nf_ray_bundle(int height, int width, float fx, float fy, float cx_w, float c
                   const float* c2w, int c2w_row_stride, float* ro, float* rd, nf_stream_t stream);
 
 /* K1 for a training batch -- replaces the full-frame get_ray_bundle plus the index gathers of one iteration
- * (train_transformed_rays.py:302, 325-330).  sel: (n, 2) int64 {row, col}; ro, rd: (n, 3), bit-identical to rows of
+ * (train_transformed_rays.py:302, 325-330).  sel: (n, 2) int64 {row, col}, or with sel_is_flat (n) int64 pixel indices
+ * row * width + col; ro, rd: (n, 3), bit-identical to rows of
  * nf_ray_bundle's output; target (n, channels) gathered from image (H, W, channels) and bg_out (n, 3) from bg (H, W, 3),
  * each optional (NULL).  bad_flag: one zeroed int on the device, set to 1 if a selected pixel lies outside the image.   */
 int nf_ray_batch(int height, int width, float fx, float fy, float cx_w, float cy_h, const float* c2w, int c2w_row_stride,
-                 const int64_t* sel, int64_t n, const float* image, int channels, const float* bg, float* ro, float* rd,
-                 float* target, float* bg_out, int* bad_flag, nf_stream_t stream);
+                 const int64_t* sel, int sel_is_flat, int64_t n, const float* image, int channels, const float* bg, float* ro,
+                 float* rd, float* target, float* bg_out, int* bad_flag, nf_stream_t stream);
+
+/* ---- K0: ray selection of a training iteration -- replaces np.random.choice(H * W, size=n, replace=False, p=probs)
+ *      (train_transformed_rays.py:320-322) -----------------------------------------------------------------------------
+ * n_select DISTINCT indices in [0, n_items), drawn without replacement with probabilities proportional to weights (>= 0, need not
+ * be normalised; items of weight 0 are never chosen).  u: n_items uniform numbers in [0, 1) from the caller's generator.
+ * idx_out (n_select) int64, ascending for n_select <= 8192 (else in arbitrary order); entries stay -1, at the end (and word 5 of
+ * the workspace is set), if fewer than n_select weights are positive.  workspace: nf_weighted_choice_workspace_bytes() bytes of device memory.                          */
+size_t nf_weighted_choice_workspace_bytes(void);
+int nf_weighted_choice(const float* weights, const float* u, int64_t n_items, int n_select, int64_t* idx_out, void* workspace,
+                       size_t workspace_bytes, nf_stream_t stream);
 
 /* ---- K2: stratified coarse depths -- replaces T:56-76 -------------------------------------------- */
 /* z: (n_rays, n_coarse).  t_vals: (n_coarse) = the caller's torch.linspace(0,1,n_coarse) table (T:50-55;

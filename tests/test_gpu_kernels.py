@@ -43,10 +43,17 @@ def test_ray_batch_equals_gathers_from_the_full_bundle(hip_lib, gpu):
         assert torch.equal(tgt.cpu(), img[sel[:, 0], sel[:, 1]]) and torch.equal(b.cpu(), bg[sel[:, 0], sel[:, 1]])
         ro2, rd2, t2, b2 = nerf.get_ray_batch(h, w, O.INTRINSICS, pose.to(gpu), sel.to(gpu))
         assert t2 is None and b2 is None and torch.equal(rd2, rd)
+        flat = (sel[:, 0] * w + sel[:, 1]).to(gpu)                                   # flat pixel indices (what choose_rays returns)
+        ro3, rd3, t3, b3 = nerf.get_ray_batch(h, w, O.INTRINSICS, pose.to(gpu), flat, img.to(gpu), bg.to(gpu), check=True)
+        assert torch.equal(rd3, rd) and torch.equal(ro3, ro) and torch.equal(t3, tgt) and torch.equal(b3, b)
     ro, rd, tgt, b = nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.zeros((0, 2), dtype=torch.int64, device=gpu))
     assert ro.shape == (0, 3) and rd.shape == (0, 3)
     with pytest.raises(IndexError):
         nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([[3, 8]], device=gpu), check=True)
+    with pytest.raises(IndexError):
+        nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([64], device=gpu), check=True)
+    with pytest.raises(IndexError):
+        nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([-1], device=gpu), check=True)    # what K0 leaves when short
     with pytest.raises(ValueError):
         nerf.get_ray_batch(8, 8, O.INTRINSICS, pose.to(gpu), torch.tensor([[3.0, 1.0]], device=gpu))
 
@@ -268,3 +275,62 @@ def test_empty_inputs(hip_lib, gpu):
         out = nerf.run_one_iter_of_nerf(512, 512, None, m, m, e(0, 3), e(0, 3), opt, mode="train", encode_position_fn=ex, encode_direction_fn=ed,
                                         expressions=c["expr"].to(gpu), background_prior=e(0, 3), latent_code=c["latent"].to(gpu))
     assert out == ()          # as the reference: no ray chunks -> zip(*[]) -> an empty tuple (T:229-290)
+
+
+def test_weighted_choice_is_the_n_smallest_exponential_keys(hip_lib, gpu):
+    """K0 (TR:320-322 on the device): the radix select must return exactly the n items with the smallest keys -log(1-u)/w --
+    checked against a float64 evaluation of the keys (boundary items may swap within fp32 rounding of the key) --, distinct,
+    in range, never an item of weight 0; ties in the key, n = 1, n = all positive items, too few positive items."""
+    from nerf import ops
+    g = torch.Generator().manual_seed(101)
+    for n_items, n in ((262144, 2048), (5000, 4948), (5000, 4900), (1000, 1), (777, 300)):     # 4948 = every item of positive weight
+        w = torch.full((n_items,), 0.1)
+        w[n_items // 5: n_items // 2] = 0.9                                   # the trainer's two-level importance map
+        w[::97] = 0.0
+        w = w / w.sum()
+        u = torch.rand(n_items, generator=g)
+        idx = ops.weighted_choice(w.to(gpu), n, u.to(gpu), check=True).cpu()
+        assert idx.shape == (n,) and idx.dtype == torch.int64
+        assert bool((idx[1:] > idx[:-1]).all()) or n == 1                     # ascending (deterministic batch order)
+        assert int(idx.min()) >= 0 and int(idx.max()) < n_items and len(set(idx.tolist())) == n
+        assert bool((w[idx] > 0).all())
+        key = -torch.log1p(-u.double()) / w.double()
+        key[w == 0] = float("inf")
+        chosen = torch.zeros(n_items, dtype=torch.bool)
+        chosen[idx] = True
+        assert float(key[chosen].max()) <= float(key[~chosen].min()) * (1 + 1e-5)
+    # ties: identical weights and identical random numbers -> any n of them
+    idx = ops.weighted_choice(torch.ones(4096, device=gpu), 100, torch.full((4096,), 0.25, device=gpu), check=True).cpu()
+    assert len(set(idx.tolist())) == 100
+    # fewer positive weights than requested: numpy raises ValueError; without the check the missing entries stay -1
+    w = torch.zeros(1000)
+    w[:10] = 1.0
+    with pytest.raises(ValueError):
+        ops.weighted_choice(w.to(gpu), 20, check=True)
+    idx = ops.weighted_choice(w.to(gpu), 20).cpu()
+    assert sorted(idx[idx >= 0].tolist()) == list(range(10)) and int((idx < 0).sum()) == 10
+    assert ops.weighted_choice(w.to(gpu), 0).numel() == 0
+
+
+def test_weighted_choice_follows_the_importance_map(hip_lib, gpu):
+    """Distribution: with the trainer's map (p = 0.9 inside the bounding box, TR:230-239) the share of chosen pixels inside the
+    box must match torch.multinomial's (same sampling scheme, independent implementation) within 4 standard errors, and every
+    call must draw fresh numbers from torch's generator (reproducible under manual_seed)."""
+    import nerf
+    H, W, n = 512, 512, 2048
+    m = torch.full((H, W), 0.1)
+    m[150:400, 120:380] = 0.9
+    p = (m / m.sum()).reshape(-1).to(gpu)
+    inside = (m.reshape(-1) > 0.5).to(gpu)
+    torch.manual_seed(5)
+    a = torch.stack([inside[nerf.choose_rays(p, n)].float().mean() for _ in range(200)])
+    b = torch.stack([inside[torch.multinomial(p, n, replacement=False)].float().mean() for _ in range(200)])
+    se = float((a.var() / 200 + b.var() / 200).sqrt())
+    print(f"share inside the box: K0 {float(a.mean()):.4f}, torch.multinomial {float(b.mean()):.4f}, standard error {se:.5f}")
+    assert abs(float(a.mean() - b.mean())) < 4 * se
+    torch.manual_seed(77)
+    i1 = nerf.choose_rays(p, n)
+    i2 = nerf.choose_rays(p, n)
+    torch.manual_seed(77)
+    j1 = nerf.choose_rays(p, n)
+    assert torch.equal(i1, j1) and not torch.equal(i1, i2)
