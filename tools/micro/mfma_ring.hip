@@ -17,7 +17,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int MODE, int STORES>
+// EPI = 1 models the layer epilogue of the real kernels: after every 8 stages each accumulator element goes through ReLU and a
+// (hi, lo) bf16 split (5 VALU instructions per element: 128 elements per lane for a 32-point wave, 64 for a 16-point wave), and
+// the next layer's B operands depend on the result -- the question being whether the second wave of a SIMD hides that VALU time
+// behind its partner's MFMAs (the waves cross a barrier every stage, so their epilogues tend to coincide).
+__device__ __forceinline__ void epi_elt(float v, unsigned& fh, unsigned& fl) {
+    const float x = __builtin_amdgcn_fmed3f(v, 0.f, __builtin_inff());
+    const __bf16 h = (__bf16)x;
+    const __bf16 l = (__bf16)(x - (float)h);
+    fh ^= (unsigned)__builtin_bit_cast(unsigned short, h);
+    fl ^= (unsigned)__builtin_bit_cast(unsigned short, l);
+}
+template <int MODE, int STORES, int EPI = 0>
 __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __restrict__ w, int n_stages, float* __restrict__ out,
                                                               float* __restrict__ sink) {
     constexpr int NW = MODE ? 8 : 4;
@@ -61,6 +72,18 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
 #pragma unroll
                     for (int t = 0; t < 8; ++t)
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k == 0 ? al[t] : ah[t], k == 1 ? bl[u] : bh[u], acc[t], 0, 0, 0);
+            }
+            if (EPI && (st & 7) == 7) {                        // a layer ends: epilogue over 8 tiles x 16 elements per lane
+                unsigned fh = 0, fl = 0;
+#pragma unroll
+                for (int t = 0; t < 8; ++t)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { epi_elt(acc[t][r], fh, fl); acc[t][r] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {                   // next layer's operands depend on the epilogue
+                    bh[0][j] = __builtin_bit_cast(__bf16, (unsigned short)((fh >> (j & 1)) & 0x3f80u));
+                    bl[0][j] = __builtin_bit_cast(__bf16, (unsigned short)((fl >> (j & 1)) & 0x3f80u));
+                }
             }
             if (STORES && (st & 7) == 7) {                     // a layer ends: 8 tiles x 4 stores of 16 B per lane
                 // STORES 1: row-major [point][256 features] (a wave instruction touches 64 lines, 16 B each);
@@ -109,6 +132,18 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
                     for (int t = 0; t < 8; ++t)
                         acc[q * 8 + t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(k == 0 ? al[t] : ah[t], k == 1 ? bl[0] : bh[0], acc[q * 8 + t], 0, 0, 0);
             }
+            if (EPI && (st & 7) == 7) {                        // a layer ends: epilogue over 16 tiles x 4 elements per lane
+                unsigned fh = 0, fl = 0;
+#pragma unroll
+                for (int t = 0; t < 16; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { epi_elt(acc[t][r], fh, fl); acc[t][r] = 0.f; }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    bh[0][j] = __builtin_bit_cast(__bf16, (unsigned short)((fh >> (j & 1)) & 0x3f80u));
+                    bl[0][j] = __builtin_bit_cast(__bf16, (unsigned short)((fl >> (j & 1)) & 0x3f80u));
+                }
+            }
             if (STORES && (st & 7) == 7) {                     // a layer ends: 16 tiles x 1 store of 16 B per lane
                 float* dst = sink + ((size_t)(blockIdx.x * 8 + wave) * 16 + (lane & 15)) * 256 + 4 * (lane >> 4);
 #pragma unroll
@@ -133,7 +168,17 @@ int main(int argc, char** argv) {
     hipMalloc(&out, grid * 512 * sizeof(float));
     float* sink; hipMalloc(&sink, (size_t)grid * 128 * 256 * sizeof(float));       // one 128-point x 256-feature tile per workgroup
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int stores = 0; stores < 4; ++stores)
+    for (int mode = 0; mode < 2; ++mode)                       // EPI: epilogue VALU work after every layer, no stores
+        for (int rep = 0; rep < 3; ++rep) {
+            hipEventRecord(e0);
+            if (mode == 0) hipLaunchKernelGGL((k_ring<0, 0, 1>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
+            else hipLaunchKernelGGL((k_ring<1, 0, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
+            hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1);
+            const double flop = (double)grid * n_stages * 128.0 * 256 * 32 * 2 * 3;
+            printf("epilogue mode %d rep %d: %.3f ms  %.1f TFLOP/s issued bf16 (%.2f of 2500)  err=%d\n", mode, rep, ms, flop / ms / 1e9, flop / ms / 1e9 / 2500, (int)hipGetLastError());
+        }
+    for (int stores = 0; stores < 1; ++stores)
     for (int mode = 0; mode < (stores >= 2 ? 1 : 2); ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipEventRecord(e0);
