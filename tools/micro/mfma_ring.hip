@@ -28,7 +28,7 @@ __device__ __forceinline__ void epi_elt(float v, unsigned& fh, unsigned& fl) {
     fh ^= (unsigned)__builtin_bit_cast(unsigned short, h);
     fl ^= (unsigned)__builtin_bit_cast(unsigned short, l);
 }
-template <int MODE, int STORES, int EPI = 0>
+template <int MODE, int STORES, int EPI = 0, int SKEW = 0>
 __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __restrict__ w, int n_stages, float* __restrict__ out,
                                                               float* __restrict__ sink) {
     constexpr int NW = MODE ? 8 : 4;
@@ -47,8 +47,9 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
     bf16x8 bh[2], bl[2];
 #pragma unroll
     for (int j = 0; j < 8; ++j) { bh[0][j] = (__bf16)(0.001f * lane); bl[0][j] = (__bf16)1e-5f; bh[1][j] = (__bf16)0.5f; bl[1][j] = (__bf16)2e-5f; }
-    issue(0, 0); issue(1, 1); issue(2, 2);
-    wait_vm<2 * PIECES>();
+    issue(0, 0); issue(1, 1);
+    if (SKEW) wait_vm<PIECES>();
+    else { issue(2, 2); wait_vm<2 * PIECES>(); }
     __builtin_amdgcn_s_barrier();
     if constexpr (MODE == 0) {
         f32x16 acc[8];
@@ -115,9 +116,16 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
         f32x4 acc[16];
 #pragma unroll
         for (int t = 0; t < 16; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        for (int st = 0; st < n_stages; ++st) {
+        // SKEW = 1: waves 4..7 (the second wave of every SIMD) run ONE STAGE behind waves 0..3, so that a wave's epilogue overlaps
+        // its partner's MFMAs.  The barrier counts global steps; at step t the leaders consume stage t, the laggers stage t - 1, and
+        // everybody issues its DMA pieces of stage t + 2 (ring of 4: t - 1, t, t + 1 landing, t + 2 in flight).
+        const int lag = (SKEW && wave >= 4) ? 1 : 0;
+        constexpr int LA = SKEW ? 2 : 3;
+        for (int step = 0; step < n_stages + (SKEW ? 1 : 0); ++step) {
+            const int st = step - lag;                         // this wave's stage
+            if (step < n_stages) issue(step + LA, (step + LA) % NBUF);
+            if (st >= 0 && st < n_stages) {
             const char* base = lds + (st % NBUF) * STAGE_BYTES + lane * 16;
-            issue(st + 3, (st + 3) % NBUF);
 #pragma unroll
             for (int q = 0; q < 2; ++q) {                      // one k-step of 32, in two half-sets of 8 tiles (register pressure)
                 bf16x8 ah[8], al[8];
@@ -148,9 +156,9 @@ __global__ void __launch_bounds__(MODE ? 512 : 256, 1) k_ring(const char* __rest
                 float* dst = sink + ((size_t)(blockIdx.x * 8 + wave) * 16 + (lane & 15)) * 256 + 4 * (lane >> 4);
 #pragma unroll
                 for (int t = 0; t < 16; ++t) *reinterpret_cast<f32x4*>(dst + 16 * t) = acc[t];
-                wait_vm<2 * PIECES + 16>();
-            } else
-            wait_vm<2 * PIECES>();
+            }
+            }
+            if (STORES) wait_vm<0>(); else if (SKEW) wait_vm<PIECES>(); else wait_vm<2 * PIECES>();
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
@@ -168,11 +176,13 @@ int main(int argc, char** argv) {
     hipMalloc(&out, grid * 512 * sizeof(float));
     float* sink; hipMalloc(&sink, (size_t)grid * 128 * 256 * sizeof(float));       // one 128-point x 256-feature tile per workgroup
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-    for (int mode = 0; mode < 2; ++mode)                       // EPI: epilogue VALU work after every layer, no stores
-        for (int rep = 0; rep < 3; ++rep) {
+    for (int mode = 0; mode < 4; ++mode)                       // EPI: epilogue VALU work after every layer, no stores
+        for (int rep = 0; rep < 3; ++rep) {                    // mode 2: 16-point waves, second wave of a SIMD one stage behind; mode 3: same, no epilogue
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL((k_ring<0, 0, 1>), dim3(grid), dim3(256), 0, 0, w, n_stages, out, sink);
-            else hipLaunchKernelGGL((k_ring<1, 0, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
+            else if (mode == 1) hipLaunchKernelGGL((k_ring<1, 0, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
+            else if (mode == 2) hipLaunchKernelGGL((k_ring<1, 0, 1, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
+            else hipLaunchKernelGGL((k_ring<1, 0, 0, 1>), dim3(grid), dim3(512), 0, 0, w, n_stages, out, sink);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             const double flop = (double)grid * n_stages * 128.0 * 256 * 32 * 2 * 3;
