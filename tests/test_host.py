@@ -263,3 +263,21 @@ def test_load_flame_data_against_live_reference(tmp_path):
                     "intrinsics": np.asarray(want[3][2], dtype=np.float64), "expr": want[5].numpy(), "bboxs": want[7].numpy()}
             blob.update({f"split{k}": np.asarray(ix) for k, ix in enumerate(want[4])})
             _check_flame(nerf.load_flame_data(base, **kw), lambda k: blob[k])
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_device(hip_lib):
+    """Argument validation of the C ABI runs on the host: NULL pointers / impossible sizes must come back as NF_EINVAL (-22),
+    empty work as 0, without a device call (this suite runs without a GPU)."""
+    import nerf._hip as H
+    lib = H.lib()
+    EINVAL = -22
+    assert lib.nf_ray_bundle(0, 8, 1.0, 1.0, 0.5, 0.5, None, 4, None, None, None) == EINVAL
+    assert lib.nf_ray_batch(8, 8, 1.0, 1.0, 4.0, 4.0, None, 4, None, 0, 0, None, 0, None, None, None, None, None, None, None) == 0      # n = 0
+    assert lib.nf_ray_batch(8, 8, 1.0, 1.0, 4.0, 4.0, None, 4, None, 0, 5, None, 0, None, None, None, None, None, None, None) == EINVAL
+    assert lib.nf_sample_coarse_ex(0, 64, 0.2, 0.8, None, None, 1, None, None) == 0                                                 # no rays
+    assert lib.nf_sample_coarse_ex(4, 0, 0.2, 0.8, None, None, 0, None, None) == EINVAL
+    assert lib.nf_weighted_choice(None, None, 100, 0, None, None, 0, None) == 0                                                    # n = 0
+    assert lib.nf_weighted_choice(None, None, 100, 10, None, None, 0, None) == EINVAL
+    assert lib.nf_weighted_choice_workspace_bytes() >= 4 * (8 + 4096)
+    assert lib.nf_paper_bwd_workspace_floats(2048 * 128) > 2176 * 2048 * 128
+    assert lib.nf_tiny_bwd_workspace_floats(4096 * 32) > 0
