@@ -50,6 +50,10 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out2, "--precision", "bf16x3"])
     b = np.asarray(Image.open(os.path.join(out2, "0001.png")))
     assert a.shape == b.shape                      # (perturb=True in validation, as shipped: images differ by sampling noise)
+    out3 = os.path.join(base, "render_h")          # split-fp16: pre-flight range probe + sticky range flag run inside the launcher
+    assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out3, "--precision", "f16x3"]) == [0, 1, 2]
+    h = np.asarray(Image.open(os.path.join(out3, "0001.png")))
+    assert h.shape == a.shape and h.std() > 0
     assert os.path.exists(os.path.join(out, "disparity", "0002.png"))
 
 
@@ -148,7 +152,7 @@ def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
     moved = [k for k in O.LCODE_KEYS if not torch.equal(ck["model_fine_state_dict"][k], ck0["model_fine_state_dict"][k])]
     assert len(moved) == len(O.LCODE_KEYS), set(O.LCODE_KEYS) - set(moved)        # every tensor of the family receives gradients
     assert float(ck["latent_codes"].abs().sum()) > 0 and np.isfinite(float(ck["loss"]))
-    for prec in ("f32", "bf16x3"):
+    for prec in ("f32", "bf16x3", "f16x3"):
         out = os.path.join(base, "render_" + prec)
         assert eval_sharded.main(["--config", cfg_path, "--checkpoint", os.path.join(logdir, "checkpoint00005.ckpt"), "--savedir", out,
                                   "--precision", prec]) == [0, 1, 2]
