@@ -37,6 +37,16 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     train_sharded.main(["--config", cfg_path, "--load-checkpoint", ck_path])
     ck2 = torch.load(os.path.join(logdir, "checkpoint00007.ckpt"), map_location="cpu")
     assert not torch.equal(ck2["latent_codes"], ck["latent_codes"])
+    # the same resume on the split-fp16 training kernels: finite loss, parameters move
+    import nerf
+    try:
+        train_sharded.main(["--config", cfg_path, "--load-checkpoint", ck_path, "--precision", "f16x3"])
+    finally:
+        nerf.set_mlp_precision("f32")
+    ck3 = torch.load(os.path.join(logdir, "checkpoint00007.ckpt"), map_location="cpu")
+    assert np.isfinite(float(ck3["loss"])) and not torch.equal(ck3["latent_codes"], ck["latent_codes"])
+    w2, w3 = ck2["model_fine_state_dict"]["layers_xyz.1.weight"], ck3["model_fine_state_dict"]["layers_xyz.1.weight"]
+    assert float((w2 - w3).abs().max()) < 0.2 * float(w2.abs().max())            # a few Adam steps apart at most (Adam moves every weight by ~lr per step)
     # eval: 3 test frames -> PNGs, identical for both precisions to within quantisation
     out = os.path.join(base, "render")
     frames = eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out, "--save-disparity-image",
