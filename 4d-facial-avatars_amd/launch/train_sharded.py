@@ -6,7 +6,8 @@ per rank per step and one flat RCCL gradient all-reduce.
 Same CLI, YAML schema and checkpoint dictionary as the reference (`iter, model_coarse_state_dict, model_fine_state_dict,
 optimizer_state_dict, loss, psnr, background, latent_codes`; two optimizer param groups).  Differences, all outside the
 hot path: ray selection (importance map, p = 0.9 inside the bbox, TR:230-239) draws on the device (nerf.choose_rays: a HIP
-radix select over exponential keys, torch's generator) instead of np.random.choice on the host; no TensorBoard; rank 0 writes checkpoints; on resume the latent codes and
+radix select over exponential keys, torch's generator) instead of np.random.choice on the host; no TensorBoard (the validation
+loss / PSNR of TR:427-505 are printed); rank 0 writes checkpoints; on resume the latent codes and
 background are restored *into* the tensors the optimizer already owns (the reference re-wraps them and the optimizer
 keeps stepping the stale ones).
 """
@@ -122,6 +123,39 @@ def main(argv=None):
         if rank == 0 and (i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1):
             print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {nerf.mse2psnr(mse.item()):.4f} "
                   f"({(time.time() - t0):.1f} s, {world} GPU)")
+        if i % cfg.experiment.validate_every == 0:
+            # TR:427-505: every validate_every iterations the first two validation frames are rendered whole (validation chunking and
+            # sample counts) with a ZERO latent code and -- as the reference does -- the expression of the training frame just used;
+            # loss = sum over the frames of 2 x fine mse (coarse mse without a fine model), divided by len(i_val) (TR:498-503).
+            # The two frames go to different ranks; one scalar is all-reduced.
+            model_c.eval()
+            if model_f is not None:
+                model_f.eval()
+            with torch.no_grad():
+                val_sum = torch.zeros(1, device=dev)
+                for j, v_idx in enumerate(i_val[:2]):
+                    if j % world != rank:
+                        continue
+                    v_img, v_pose, _ = stager.fetch(int(v_idx))
+                    v_ro, v_rd = nerf.get_ray_bundle(H, W, intrinsics, v_pose)
+                    v_out = nerf.run_one_iter_of_nerf(
+                        H, W, intrinsics, model_c, model_f, v_ro, v_rd, cfg, mode="validation", encode_position_fn=enc_xyz,
+                        encode_direction_fn=enc_dir, expressions=expr,
+                        background_prior=background.view(-1, 3) if background is not None else None,
+                        latent_code=torch.zeros(32, device=dev))
+                    v_loss = nerf.img2mse(v_out[0][..., :3], v_img[..., :3])
+                    if v_out[3] is not None:
+                        v_loss = 2.0 * nerf.img2mse(v_out[3][..., :3], v_img[..., :3])
+                    val_sum += v_loss
+                if world > 1:
+                    torch.distributed.all_reduce(val_sum)
+                val_loss = float(val_sum) / max(len(i_val), 1)
+            if rank == 0:
+                print(f"[VAL] Iter: {i} Validation loss: {val_loss:.6f} Validation PSNR: {nerf.mse2psnr(val_loss):.4f} "
+                      f"({(time.time() - t0):.1f} s)")
+            model_c.train()
+            if model_f is not None:
+                model_f.train()
         if rank == 0 and (i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1):
             psnr = nerf.mse2psnr(mse.item())
             torch.save({"iter": i, "model_coarse_state_dict": model_c.state_dict(),

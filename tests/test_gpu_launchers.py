@@ -22,7 +22,14 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     cfg_path = os.path.join(base, "config.yml")
     with open(cfg_path, "w") as f:
         yaml.safe_dump(MS.config(os.path.join(base, "data"), os.path.join(base, "logs")), f)
-    logdir = train_sharded.main(["--config", cfg_path])
+    import contextlib, io
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        logdir = train_sharded.main(["--config", cfg_path])
+    log = buf.getvalue()
+    print(log)
+    val = [l for l in log.splitlines() if l.startswith("[VAL] Iter: 0 ")]          # TR:427-505: validation at iteration 0
+    assert len(val) == 1 and 0.0 < float(val[0].split("Validation PSNR: ")[1].split()[0]) < 60.0
     ck_path = os.path.join(logdir, "checkpoint00005.ckpt")
     assert os.path.exists(os.path.join(logdir, "checkpoint00000.ckpt")) and os.path.exists(ck_path)
     ck = torch.load(ck_path, map_location="cpu")
