@@ -55,6 +55,14 @@ def to_uint8(img: torch.Tensor) -> torch.Tensor:
     return (img.clamp(0.0, 1.0) * 255.0).to(torch.uint8)
 
 
+def jet_u8(x):
+    """(H, W) -> (H, W, 3) uint8: x scaled to its own [min, max] (imshow's autoscale) through matplotlib's 'jet' map
+    (piecewise-linear: r = clamp(1.5 - |4 t - 3|), g = clamp(1.5 - |4 t - 2|), b = clamp(1.5 - |4 t - 1|))."""
+    t = (x - x.min()) / (x.max() - x.min() + 1e-12)
+    rgb = torch.stack([1.5 - (4 * t - 3).abs(), 1.5 - (4 * t - 2).abs(), 1.5 - (4 * t - 1).abs()], dim=-1).clamp(0, 1)
+    return to_uint8(rgb)
+
+
 def main(argv=None):
     keep = nerf.get_mlp_precision()          # the precision switch is process-global: leave it as the caller had it
     try:
@@ -69,6 +77,9 @@ def _main(argv=None):
     ap.add_argument("--checkpoint", type=str, required=True)
     ap.add_argument("--savedir", type=str, required=True)
     ap.add_argument("--save-disparity-image", action="store_true")
+    ap.add_argument("--save-error-image", action="store_true",
+                    help="also write the photometric error map of EV:160-182, 492-497 (savedir/error): per-pixel L2 distance to the "
+                         "test image through the jet colour map, at the native resolution (the reference saves a matplotlib figure)")
     ap.add_argument("--save-normals", action="store_true", help="also write the cleaned normal map of EV:469-471 (savedir/normals)")
     ap.add_argument("--precision", choices=["f32", "f16x3", "bf16x3"], default="f32",
                     help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; bf16x3 = split-bf16 kernels, 3x faster, "
@@ -110,6 +121,8 @@ def _main(argv=None):
     writer = PngWriter()
     if args.save_normals:
         os.makedirs(os.path.join(args.savedir, "normals"), exist_ok=True)
+    if args.save_error_image:
+        os.makedirs(os.path.join(args.savedir, "error"), exist_ok=True)
     for i in mine:
         t0 = time.time()
         row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
@@ -130,6 +143,9 @@ def _main(argv=None):
             disp = out[4] if out[4] is not None else out[1]
             d = (disp - disp.min()) / (disp.max() - disp.min() + 1e-12)
             writer.submit(to_uint8(d), os.path.join(args.savedir, "disparity", f"{i:04d}.png"))
+        if args.save_error_image:
+            gt = images[i].to(dev)[..., :3].reshape(H, W, 3)
+            writer.submit(jet_u8(torch.linalg.norm(gt - rgb[..., :3], dim=-1)), os.path.join(args.savedir, "error", f"{i:04d}.png"))
         times.append(time.time() - t0)
     torch.cuda.synchronize()
     writer.close()

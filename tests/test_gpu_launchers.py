@@ -57,7 +57,9 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     # eval: 3 test frames -> PNGs, identical for both precisions to within quantisation
     out = os.path.join(base, "render")
     frames = eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out, "--save-disparity-image",
-                                "--save-normals", "--precision", "f32"])
+                                "--save-normals", "--save-error-image", "--precision", "f32"])
+    err = np.asarray(__import__("PIL.Image").Image.open(os.path.join(out, "error", "0002.png")))
+    assert err.shape == (32, 32, 3) and err.std() > 0                         # EV:492-497 (native resolution, jet map)
     assert np.asarray(__import__("PIL.Image").Image.open(os.path.join(out, "normals", "0000.png"))).shape == (31, 31, 3)
     assert frames == [0, 1, 2]
     from PIL import Image
