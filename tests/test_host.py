@@ -281,3 +281,17 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device(hip_lib):
     assert lib.nf_weighted_choice_workspace_bytes() >= 4 * (8 + 4096)
     assert lib.nf_paper_bwd_workspace_floats(2048 * 128) > 2176 * 2048 * 128
     assert lib.nf_tiny_bwd_workspace_floats(4096 * 32) > 0
+
+
+def test_launcher_host_helpers():
+    """Pure host-side pieces of the launchers: the importance map of TR:230-239 (p = 0.9 inside the bounding box, normalised) and
+    the jet colour map of the error image (matplotlib's piecewise-linear 'jet' at its anchor points)."""
+    sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
+    from launch import eval_sharded, train_sharded
+    m = train_sharded.importance_maps(np.array([[2, 6, 1, 5]]), 8, 8)[0].reshape(8, 8)
+    assert abs(m.sum() - 1.0) < 1e-12 and np.allclose(m[2:6, 1:5] / m[0, 0], 9.0)
+    assert np.count_nonzero(m == m[0, 0]) == 64 - 16
+    x = torch.tensor([[0.0, 0.125, 0.375], [0.5, 0.625, 1.0]])
+    got = eval_sharded.jet_u8(x).tolist()
+    want = [[[0, 0, 127], [0, 0, 255], [0, 255, 255]], [[127, 255, 127], [255, 255, 0], [127, 0, 0]]]
+    assert got == want, got
