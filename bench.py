@@ -32,6 +32,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
+import subprocess
 import sys
 import time
 
@@ -302,6 +304,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
                        "rays_per_step": n_rays * world, "parallelism": f"dp{world}",
                        "mlp_precision": args.precision, "family": args.family}}
         if emit:
+            line["config"]["device"] = device_info(dev)
             print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -392,6 +395,25 @@ def cpu_baseline_tiny(params, pose, focal, reps=3):
         cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
     return {"value": 4096 / (cpu_ms * 1e-3), "unit": "rays/s", "ms_per_image": cpu_ms, "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} whole 64x64x32 images"}
+
+
+def device_info(dev):
+    """What the box reports (re-derive the peaks from the clocks of the GPU box): CUs x 256 fp32-MFMA FLOP per clock x
+    the engine clock, beside the vendor figure the roofline is priced against."""
+    p = torch.cuda.get_device_properties(dev)
+    mhz = float(getattr(p, "clock_rate", 0)) / 1e3
+    if mhz <= 0:                                                        # torch on ROCm reports no clock: ask rocminfo (gfx agent's max clock)
+        try:
+            txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
+            blocks = [b for b in txt.split("*******") if "gfx950" in b and "Max Clock Freq" in b]
+            if blocks:
+                mhz = float(re.search(r"Max Clock Freq\. \(MHz\):\s*(\d+)", blocks[0]).group(1))
+        except Exception:
+            mhz = 0.0
+    cus = int(p.multi_processor_count)
+    return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": cus, "engine_clock_mhz": mhz,
+            "hbm_gib": round(p.total_memory / 2 ** 30, 1),
+            "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
 
 
 def pmc_traffic(precision, timeout=240):
@@ -554,7 +576,7 @@ def main():
         "config": {"workload": "configs[1]: paper-model eval forward, 512x512 frame, 64+128 samples, chunksize 65536, "
                                "perturb on, expression+latent conditioned, background prior; frames sharded over GPUs",
                    "rays_per_step": H * W, "points_per_ray": N_COARSE + N_COARSE + N_FINE, "parallelism": f"frames x{world}",
-                   "mlp_precision": args.precision},
+                   "mlp_precision": args.precision, "device": device_info(dev)},
     }
 
     # ---- the same K frames (same warm-up, same bracketing) in the other arithmetics, beside the headline -----------------
