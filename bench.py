@@ -304,7 +304,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
                        "rays_per_step": n_rays * world, "parallelism": f"dp{world}",
                        "mlp_precision": args.precision, "family": args.family}}
         if emit:
-            line["config"]["device"] = device_info(dev)
+            result["config"]["device"] = device_info(dev)
             print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
