@@ -273,6 +273,122 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
 }
 
+// Training forward (exact f32): the same arithmetic as k_paper_mlp_fwd, plus everything the backward needs in `saved`
+// (layout nfl::S_*): every layer output as row-major [n][width] matrices for the weight-gradient GEMMs -- copied out of
+// the wave's LDS slab as whole 128-byte lines from inside the NEXT layer's K loop (nf_mma_from_lds_copy) -- and the ReLU
+// bit masks the dX chain applies (nf_relu_with_mask; 8 bytes per lane, tile and layer).
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
+                     const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z,
+                     int64_t n_points, int S, float* __restrict__ raw, float* __restrict__ saved) {
+    using namespace nfl;
+    static_assert(NT == 2, "the copy schedule below is written for 32-point slabs");
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;                       // wave-uniform; no barriers anywhere below
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
+    const int64_t n = n_points;
+    auto sec = [&](int s, int width) { return nf_slab_copy(saved, s, width, p0, n); };
+
+    // ---- inputs: pts = ro + rd*z (T:78), PE fragments, dir fragment -----------------------------
+    f32x4 pe[NT][4];
+    f32x4 dirf[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const int64_t ray = p / S;
+        const float zz = z[p];
+        const float dx = rd[ray * 3 + 0], dy = rd[ray * 3 + 1], dz = rd[ray * 3 + 2];
+        const float px = nf_add(ro[ray * 3 + 0], nf_mul(dx, zz));
+        const float py = nf_add(ro[ray * 3 + 1], nf_mul(dy, zz));
+        const float pz = nf_add(ro[ray * 3 + 2], nf_mul(dz, zz));
+        nf_encode_point(px, py, pz, g, pe[t]);
+        float s, cs;
+        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
+        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+        // dir slots: 64 B per point, the 16 points of a tile are one contiguous KiB
+        if (p0 + 16 * t + c < n_points) *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) act4[nf_act_idx4(16 * t + c, 4 * j + g)] = pe[t][j];       // PE slots 16 j + 4 g .. + 3
+    }
+    {   // PE rows (64 slots = 256 B per point): four rows per instruction, before layers_xyz.0's output takes the slab
+        const NfSlabCopy cp = sec(S_PE, 64);
+#pragma unroll
+        for (int k = 0; k < 16 * NT / 4; ++k) nf_copy_rows<16>(act4, cp, k, lane);
+    }
+
+    f32x4 acc[NT][16];
+    uint2 m[NT];
+#define NF_FINISH_SAVE(NO_, MASKL_)                                                                  \
+    do {                                                                                            \
+        if ((MASKL_) >= 0) {                                                                        \
+            nf_relu_with_mask<NT, NO_>(acc, m);                                                     \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
+                if (p0 + 16 * t < n) *nf_mask_ptr(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t];    \
+        }                                                                                           \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                              \
+    } while (0)
+    // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
+    NF_FINISH_SAVE(16, 0);
+    // ---- layers_xyz.1, .2 (each K loop also streams the previous layer's output to `saved`) -------
+    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L1 / 4, 16, act4, lane, sec(S_H0, 256));
+    NF_FINISH_SAVE(16, 1);
+    nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L2 / 4, 16, act4, lane, sec(S_H1, 256));
+    NF_FINISH_SAVE(16, 2);
+    // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane, sec(S_H2, 256));
+    NF_FINISH_SAVE(16, 3);
+    // ---- layers_xyz.4, .5 ------------------------------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L4 / 4, 16, act4, lane, sec(S_H3, 256));
+    NF_FINISH_SAVE(16, 4);
+    nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L5 / 4, 16, act4, lane, sec(S_H4, 256));
+    NF_FINISH_SAVE(16, 5);
+    // ---- fc_feat (no activation, M:250) ------------------------------------------------------------
+    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_FEAT / 4, 16, act4, lane, sec(S_H5, 256));
+    NF_FINISH_SAVE(16, -1);
+    // ---- layers_dir.0 : [feat | dir slots] -> 128, ReLU; tile 8 row 0 = fc_alpha(feat) (Q2) ----------
+    nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
+    nf_mma_from_lds_copy<NT, 9, 64, 4>(acc, W + OFF_D0 / 4, 16, act4, lane, sec(S_FEAT, 256));
+    nf_mma_from_regs<NT, 9, 1>(acc, W + OFF_D0 / 4 + 16 * 9 * 64, dirf, lane);
+    float sigma_raw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
+    NF_FINISH_SAVE(8, 6);
+    // ---- layers_dir.1, .2 (128-wide rows: two per copy instruction) -------------------------------------
+    nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
+    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, W + OFF_D1 / 4, 8, act4, lane, sec(S_D0, 128));
+    NF_FINISH_SAVE(8, 7);
+    nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
+    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, W + OFF_D2 / 4, 8, act4, lane, sec(S_D1, 128));
+    NF_FINISH_SAVE(8, 8);
+#undef NF_FINISH_SAVE
+    // ---- fc_rgb -------------------------------------------------------------------------------------------
+    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
+    nf_mma_from_lds_copy<NT, 1, 32, 4>(acc, W + OFF_RGB / 4, 8, act4, lane, sec(S_D2, 128));
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t p = p0 + 16 * t + c;
+            if (p < n_points)
+                reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+        }
+    }
+}
+
 static int nf_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
@@ -283,7 +399,11 @@ static int nf_launch_fwd(const float* packed, const float* cond, const float* ro
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    if (saved)
+    if (saved && n_points >= ((int64_t)1 << 22)) return NF_EINVAL;       // the save path addresses a section with 32-bit byte offsets (1 KiB per point)
+    if (saved && !nf_legacy_train())
+        hipLaunchKernelGGL((k_paper_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
+    else if (saved)
         hipLaunchKernelGGL((k_paper_mlp_fwd<NT, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
@@ -297,7 +417,8 @@ extern "C" int nf_paper_mlp_fwd(const float* packed, const float* cond, const fl
     return nf_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, nullptr, stream);
 }
 
-extern "C" size_t nf_paper_saved_floats(int64_t n_points) { return (size_t)nfl::SAVED_PER_POINT * (size_t)n_points; }
+// + one point tile of mask words: the exact-f32 masks are kept per 16-point tile, ceil(n / 16) of them per layer
+extern "C" size_t nf_paper_saved_floats(int64_t n_points) { return (size_t)nfl::SAVED_PER_POINT * (size_t)n_points + 9 * 128; }
 
 extern "C" int nf_paper_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd,
                                       const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,

@@ -130,6 +130,88 @@ k_paper_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restric
 #undef NF_BWD_FINISH
 }
 
+// The chain as shipped: ReLU masks come from the bit masks the training forward left in section S_MASK (288 bytes per
+// point, all nine layers fetched at kernel entry) instead of 7.7 KB per point of saved activations read synchronously at
+// every layer boundary, and every dZ section leaves through the wave's LDS slab as whole lines, from inside the next
+// layer's K loop (nf_mma_from_lds_copy) -- see nf_mlp_dev.h.  Arithmetic and results are those of k_paper_mlp_bwd_chain.
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_paper_mlp_bwd_chain_masks(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
+                            int64_t n_points, float* __restrict__ dz) {
+    using namespace nfl;
+    static_assert(NT == 2, "the copy schedule below is written for 32-point slabs");
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
+    const int64_t n = n_points;
+    auto sec = [&](int zs, int width) { return nf_slab_copy(dz, zs, width, p0, n); };
+
+    uint2 m[9][NT];                                   // layers h0..h5, layers_dir.0..2
+#pragma unroll
+    for (int l = 0; l < 9; ++l)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            m[l][t] = p0 + 16 * t < n ? *nf_mask_ptr(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
+    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int64_t p = p0 + 16 * t + c;
+        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
+        frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
+        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
+    }
+    f32x4 acc[NT][16];
+#define NF_BWD_FINISH_M(NO_, MASKL_)                                                  \
+    do {                                                                              \
+        if ((MASKL_) >= 0) nf_apply_mask<NT, NO_>(acc, m[(MASKL_) < 0 ? 0 : (MASKL_)]); \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                \
+    } while (0)
+    // d(layers_dir.2 out) = d rgb . fc_rgb.weight ; mask by layers_dir.2's ReLU
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
+    NF_BWD_FINISH_M(8, 8);
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, WT + OFFT_D2 / 4, 8, act4, lane, sec(Z_D2, 128));
+    NF_BWD_FINISH_M(8, 7);
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, WT + OFFT_D1 / 4, 8, act4, lane, sec(Z_D1, 128));
+    NF_BWD_FINISH_M(8, 6);
+    // d feat = dZ_D0 . layers_dir.0.weight[:, :256] + d sigma * fc_alpha.weight   (no activation on feat)
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 32, 4>(acc, WT + OFFT_D0 / 4, 8, act4, lane, sec(Z_D0, 128));
+    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_D0 / 4 + 8 * 16 * 64, frag_sig, lane);
+    NF_BWD_FINISH_M(16, -1);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_FEAT / 4, 16, act4, lane, sec(Z_FEAT, 256));
+    NF_BWD_FINISH_M(16, 5);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L5 / 4, 16, act4, lane, sec(Z_L5, 256));
+    NF_BWD_FINISH_M(16, 4);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L4 / 4, 16, act4, lane, sec(Z_L4, 256));
+    NF_BWD_FINISH_M(16, 3);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L3 / 4, 16, act4, lane, sec(Z_L3, 256));     // hidden columns of the skip layer only
+    NF_BWD_FINISH_M(16, 2);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L2 / 4, 16, act4, lane, sec(Z_L2, 256));
+    NF_BWD_FINISH_M(16, 1);
+    nf_zero_acc<NT, 16>(acc);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L1 / 4, 16, act4, lane, sec(Z_L1, 256));
+    NF_BWD_FINISH_M(16, 0);
+#undef NF_BWD_FINISH_M
+    {   // the last section has no K loop behind it
+        const NfSlabCopy cp = sec(Z_L0, 256);
+#pragma unroll 4
+        for (int k = 0; k < 16 * NT; ++k) nf_copy_rows<64>(act4, cp, k, lane);
+    }
+}
+
 // =================================================================================================
 // B2: weight-gradient GEMMs (generic kernel in nf_mlp_dw.h); the paper model's job table
 // =================================================================================================
@@ -166,6 +248,79 @@ static void nf_build_dw_jobs(NfDwJob* j) {
     add(1, 0, 4, 0, 4, S_FEAT, 256, 0, 128, G_ALPHA, 256, -1);             // row 3 (d sigma): fc_alpha.weight
     add(1, 0, 4, 0, 4, S_FEAT, 256, 128, 128, G_ALPHA + 128, 256, -1);
     // n == NF_DW_JOBS by construction
+}
+
+// The same 36 products as groups of four that share operand panels (k_dw_gemm_lds, nf_mlp_dw.h)
+#define NF_DW_GROUPS 9
+
+static void nf_build_dw_groups(NfDwGroup* gr) {
+    using namespace nfl;
+    int n = 0;
+    const NfDwPanel off{-1, 0, 0, 0, 0};
+    auto fresh = [&]() -> NfDwGroup& {
+        NfDwGroup& g = gr[n++];
+        for (auto& p : g.panel) p = off;
+        return g;
+    };
+    auto job = [](const NfDwGroup& g, int a, int b, int out_off, int ldo, int cs) {
+        return NfDwWaveJob{a, b, g.panel[a].valid, g.panel[b].valid, out_off, ldo, cs};
+    };
+    // a 256 x 256 layer: panels {dZ lo, dZ hi, X lo, X hi}, waves = the 2 x 2 blocks of the product
+    auto layer256 = [&](int zsec, int bsec, int gout, int cs) {
+        NfDwGroup& g = fresh();
+        for (int h = 0; h < 2; ++h) {
+            g.panel[h] = NfDwPanel{0, zsec, 256, 128 * h, 128};
+            g.panel[2 + h] = NfDwPanel{2, bsec, 256, 128 * h, 128};
+        }
+        for (int nb = 0; nb < 2; ++nb)
+            for (int kb = 0; kb < 2; ++kb)
+                g.wave[2 * nb + kb] = job(g, nb, 2 + kb, gout + 128 * nb * 256 + 128 * kb, 256, (kb == 0 && cs >= 0) ? cs + 128 * nb : -1);
+    };
+    layer256(Z_L1, S_H0, G_L1, CS_L0 + 256);
+    layer256(Z_L2, S_H1, G_L2, CS_L0 + 512);
+    layer256(Z_L3, S_H2, G_L3B, -1);
+    layer256(Z_L4, S_H3, G_L4, CS_L0 + 1024);
+    layer256(Z_L5, S_H4, G_L5, CS_L0 + 1280);
+    layer256(Z_FEAT, S_H5, G_FEAT, CS_L0 + 1536);
+    {   // the four products against the positional encoding: (dZ_L0 | dZ_L3) x PE
+        NfDwGroup& g = fresh();
+        for (int h = 0; h < 2; ++h) {
+            g.panel[h] = NfDwPanel{0, Z_L0, 256, 128 * h, 128};
+            g.panel[2 + h] = NfDwPanel{0, Z_L3, 256, 128 * h, 128};
+        }
+        g.panel[4] = NfDwPanel{2, S_PE, 64, 0, 64};
+        for (int nb = 0; nb < 2; ++nb) {
+            g.wave[nb] = job(g, nb, 4, G_L0 + 128 * nb * 64, 64, CS_L0 + 128 * nb);
+            g.wave[2 + nb] = job(g, 2 + nb, 4, G_L3A + 128 * nb * 64, 64, CS_L0 + 768 + 128 * nb);
+        }
+    }
+    {   // dZ_D0 x (feat | dir slots), dZ_D1 x d0
+        NfDwGroup& g = fresh();
+        g.panel[0] = NfDwPanel{0, Z_D0, 128, 0, 128};
+        g.panel[1] = NfDwPanel{2, S_FEAT, 256, 0, 128};
+        g.panel[2] = NfDwPanel{2, S_FEAT, 256, 128, 128};
+        g.panel[3] = NfDwPanel{2, S_DIRF, 16, 0, 16};
+        g.panel[4] = NfDwPanel{0, Z_D1, 128, 0, 128};
+        g.panel[5] = NfDwPanel{2, S_D0, 128, 0, 128};
+        g.wave[0] = job(g, 0, 1, G_D0A, 256, CS_D0);
+        g.wave[1] = job(g, 0, 2, G_D0A + 128, 256, -1);
+        g.wave[2] = job(g, 0, 3, G_D0B, 16, -1);
+        g.wave[3] = job(g, 4, 5, G_D1, 128, CS_D0 + 128);
+    }
+    {   // dZ_D2 x d1, d_raw x (d2 | feat): rows 0..2 = fc_rgb.weight, row 3 (d sigma) = fc_alpha.weight, cs = the 4 output-bias gradients
+        NfDwGroup& g = fresh();
+        g.panel[0] = NfDwPanel{0, Z_D2, 128, 0, 128};
+        g.panel[1] = NfDwPanel{2, S_D1, 128, 0, 128};
+        g.panel[2] = NfDwPanel{1, 0, 4, 0, 4};
+        g.panel[3] = NfDwPanel{2, S_D2, 128, 0, 128};
+        g.panel[4] = NfDwPanel{2, S_FEAT, 256, 0, 128};
+        g.panel[5] = NfDwPanel{2, S_FEAT, 256, 128, 128};
+        g.wave[0] = job(g, 0, 1, G_D2, 128, CS_D0 + 256);
+        g.wave[1] = job(g, 2, 3, G_RGB, 128, CS_RGB);
+        g.wave[2] = job(g, 2, 4, G_ALPHA, 256, -1);
+        g.wave[3] = job(g, 2, 5, G_ALPHA + 128, 256, -1);
+    }
+    // n == NF_DW_GROUPS by construction
 }
 
 // =================================================================================================
@@ -263,6 +418,7 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
 }
 
 static NfDwJobTable g_paper_jobs;
+static NfDwGroupTable g_paper_groups;
 
 // defined in nf_mlp_bf16_bwd.hip / nf_mlp_f16_bwd.hip
 int nfb_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
@@ -281,6 +437,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     if (packed_t_f16) split_dw = true;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
+    if (n_points >= ((int64_t)1 << 22)) return NF_EINVAL;                // as the training forward: 32-bit byte offsets into a dZ section
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
@@ -311,16 +468,28 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
         const int rc2 = nfb_launch_bwd_chain_bf16(packed_t_bf16, saved, d_raw, n_points, dz, nullptr, stream);
         if (rc2) return rc2;
     } else {
-        hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
-                           n_points, dz);
+        if (nf_legacy_train())
+            hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
+                               n_points, dz);
+        else
+            hipLaunchKernelGGL((k_paper_mlp_bwd_chain_masks<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved,
+                               d_raw, n_points, dz);
     }
     if (split_dw) {
         const int rc3 = packed_t_f16 ? nfb_launch_dw_gemm_f16(0, dz, d_raw, saved, n_points, pps, ns, slabs, gscale, stream)
                                      : nfb_launch_dw_gemm_bf16(0, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc3) return rc3;
     } else {
-        hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
-                           saved, n_points, pps, slabs);
+        if (nf_legacy_train()) {
+            hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
+                               saved, n_points, pps, slabs);
+        } else {
+            const NfDwGroup* groups = nullptr;
+            const int rcg = g_paper_groups.get(NF_DW_GROUPS, nf_build_dw_groups, &groups);
+            if (rcg) return rcg;
+            hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(NF_DW_GROUPS, ns), dim3(64 * NF_DW_WAVES), 0, s, groups, (int)SLAB_FLOATS, dz, d_raw, saved,
+                               n_points, pps, slabs);
+        }
     }
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
     NfGradOffsets offs;
@@ -364,5 +533,10 @@ extern "C" int nf_selftest_dw_tables_f32(void) {
     NfDwJob jobs[NF_DW_JOBS];
     nf_build_dw_jobs(jobs);
     const long paper = 2L * 256 * 64 + 6L * 65536 + 128L * 272 + 2L * 128 * 128 + 4L * 128 + 4L * 256 + 7 * 256 + 3 * 128 + 4;
-    return nf_check_dw_jobs(jobs, NF_DW_JOBS, nfl::SLAB_FLOATS, paper);
+    const int rc = nf_check_dw_jobs(jobs, NF_DW_JOBS, nfl::SLAB_FLOATS, paper);
+    if (rc) return rc;
+    NfDwGroup groups[NF_DW_GROUPS];
+    nf_build_dw_groups(groups);
+    const int rg = nf_check_dw_groups(groups, NF_DW_GROUPS, nfl::SLAB_FLOATS, paper);
+    return rg ? rg - 100 : 0;
 }

@@ -167,3 +167,111 @@ __device__ __forceinline__ void nf_mask_by_saved(f32x4 (&acc)[NT][16], const flo
     }
 }
 
+
+// =====================================================================================================================
+// Training kernels of the paper model (exact f32): line-wide saves and ReLU bit masks
+// =====================================================================================================================
+// After nf_store_act the wave's LDS slab holds a layer's [16 NT points][width] outputs, and a point's row is contiguous in
+// the row-major global matrix the weight-gradient GEMMs read.  So 64 lanes x 16 B copy one 256-wide row (1 KiB), two 128-wide
+// rows or four 64-wide rows per instruction: every global store covers whole 128-byte lines (the register-direct
+// nf_store_global writes 16 rows x 64 B per instruction, which the memory system takes at a third of that rate).  The copies
+// are issued from inside the NEXT layer's K loop -- a few rows per iteration, under its MFMAs -- instead of as one burst at
+// the layer boundary, where all 1024 waves of the chip used to queue their 32 KiB behind one another while the matrix
+// pipes idled (one in-order wave per SIMD: nothing else can run).
+// Stores go through a buffer descriptor that covers exactly the section: rows of points past n (the last wave's partial
+// tile) fall outside it and are dropped by the hardware's range check -- no predicate, no branch in the K loop, so the LDS
+// reads of the copy can be scheduled ahead of their stores like any other load.
+typedef unsigned nf_u32x4 __attribute__((ext_vector_type(4)));
+struct NfSlabCopy {
+    __amdgpu_buffer_rsrc_t rsrc;      // [n][W] row-major section
+    unsigned row0_b;                  // byte offset of the slab's first row
+};
+// section `sec` ([n][width] floats at base + sec * n) as a copy target for the slab that starts at point p0
+__device__ __forceinline__ NfSlabCopy nf_slab_copy(float* base, int sec, int width, int64_t p0, int64_t n) {
+    NfSlabCopy c;
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc(base + (int64_t)sec * n, (short)0, (int)((unsigned)n * (unsigned)(4 * width)), 0x00020000);
+    c.row0_b = (unsigned)p0 * (unsigned)(4 * width);
+    return c;
+}
+
+// copy instruction `inst` of a slab whose rows are W4 float4 wide (64 / W4 rows per instruction)
+template <int W4>
+__device__ __forceinline__ void nf_copy_rows(const f32x4* act4, const NfSlabCopy& cp, int inst, int lane) {
+    constexpr int RPI = 64 / W4;
+    const int p = inst * RPI + lane / W4, q = lane % W4;
+    const f32x4 v = act4[nf_act_idx4(p, q)];
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, 0);
+}
+
+// nf_mma_from_lds + the deferred copy of the slab it reads (the previous layer's output, W4 float4 per row): PER copy
+// instructions per loop iteration; (nch / 2) * PER must equal the 16 NT * W4 / 64 instructions the slab takes.
+template <int NT, int NO, int W4, int PER>
+__device__ __forceinline__ void nf_mma_from_lds_copy(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4,
+                                                     int lane, const NfSlabCopy& cp) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 wa[NO], wb[NO];
+    nf_load_w<NT, NO>(wa, wsec, lane);
+#pragma unroll 1
+    for (int ni = 0; ni < nch; ni += 2) {
+        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
+        f32x4 b[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
+        nf_mma_chunk<NT, NO>(acc, wa, b);
+#pragma unroll
+        for (int k = 0; k < PER; ++k) nf_copy_rows<W4>(act4, cp, (ni >> 1) * PER + k, lane);
+        if (ni + 2 < nch) nf_load_w<NT, NO>(wa, wsec + (size_t)(ni + 2) * NO * 64, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
+        nf_mma_chunk<NT, NO>(acc, wb, b);
+    }
+}
+
+// ReLU bit masks of the exact-f32 kernels: section nfl::S_MASK of `saved`, [9 layers][ceil(n / 16) point tiles][64 lanes][2 dwords];
+// bit 4 no + r of lane (g, c) <-> feature 16 no + 4 g + r of point 16 tile + c (the D-register order of the f32 MFMA tiles), i.e.
+// exactly what the lane holds: one 8-byte store per lane and tile in the forward, one 8-byte load in the backward chain.
+// (The split-bf16/fp16 kernels keep their own bit order in the same section; a `saved` buffer goes back to the family that wrote it.)
+__device__ __forceinline__ uint2* nf_mask_ptr(float* saved, int64_t n, int layer, int64_t tile, int lane) {
+    const int64_t n_tiles = (n + 15) >> 4;
+    return reinterpret_cast<uint2*>(saved + (int64_t)nfl::S_MASK * n) + ((int64_t)layer * n_tiles + tile) * 64 + lane;
+}
+
+// acc = max(acc, 0); returns the mask bits of the lane ([x > 0], exact also for +-0: the int view of a float is > 0 iff the float is)
+template <int NT, int NO>
+__device__ __forceinline__ void nf_relu_with_mask(f32x4 (&acc)[NT][16], uint2 (&m)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        uint32_t w[2] = {0u, 0u};
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            f32x4 v = acc[t][no];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int xi = __float_as_int(v[r]);
+                const int bit = xi > 1 ? 1 : (xi < 0 ? 0 : xi);                   // v_med3_i32(xi, 0, 1)
+                w[no >> 3] |= (uint32_t)bit << (4 * (no & 7) + r);
+                v[r] = fmaxf(v[r], 0.f);
+            }
+            acc[t][no] = v;
+        }
+        m[t] = make_uint2(w[0], w[1]);
+    }
+}
+
+// acc *= mask bits
+template <int NT, int NO>
+__device__ __forceinline__ void nf_apply_mask(f32x4 (&acc)[NT][16], const uint2 (&m)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            const uint32_t w = no < 8 ? m[t].x : m[t].y;
+            f32x4 v = acc[t][no];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int keep = ((int)(w << (31 - (4 * (no & 7) + r)))) >> 31;     // v_bfe_i32: 0 or -1
+                v[r] = __int_as_float(__float_as_int(v[r]) & keep);
+            }
+            acc[t][no] = v;
+        }
+}

@@ -115,6 +115,230 @@ k_dw_gemm(const NfDwJob* __restrict__ jobs, int n_jobs, int slab_floats, const f
 }
 
 
+// =================================================================================================
+// B2, shared-panel form (the paper model's exact-f32 training path).
+// Same arithmetic, slices and per-element accumulation order as k_dw_gemm -- results are bit-identical -- but a WORKGROUP is
+// a GROUP of four 128 x 128 products that read common operand panels (the 2 x 2 blocks of one 256 x 256 product; the four
+// products against the positional encoding; ...):
+//   * a panel = 16 points x 128 columns of dZ / d_raw / saved activations = 8 KiB; the group's panels of a 16-point chunk are
+//     fetched ONCE per workgroup, by LDS-DMA (global_load_lds_dwordx4: two full rows = 1 KiB per wave instruction, no registers
+//     in between), into a three-stage ring, three chunks ahead of the MFMAs.  k_dw_gemm fetched every panel once per JOB (twice
+//     per 256 x 256 layer: 35 KB per point against 17.7 KB of distinct data, 3.2 TB/s) through 64 staging registers;
+//   * eight waves, two per SIMD: wave 2 j + h owns the 128 x 64 half h of product j (128 accumulator registers, 48 operand
+//     registers).  Two in-order waves on a SIMD cover each other's LDS reads, DMA issue and waits with MFMAs, and the
+//     compiler has register room to interleave the loads the way the sched_group_barrier sequence asks for; a wave whose half
+//     lies past a narrow panel's columns (PE: 64, dir slots: 16) issues no MFMAs and leaves the matrix pipe to its partner;
+//   * one raw s_barrier per chunk; the wait before it is a counted vmcnt that leaves the newest chunks' DMA in flight.
+// =================================================================================================
+#define NF_DW_MAXP 6                                  // operand panels per group
+#define NF_DW_STAGES 3
+#define NF_DW_PANEL_BYTES (16 * 128 * 4)
+#define NF_DW_STAGE_BYTES (NF_DW_MAXP * NF_DW_PANEL_BYTES)
+#define NF_DW_WAVES 8
+struct NfDwPanel {
+    int kind;        // 0: dz section, 1: d_raw, 2: saved section; -1: unused slot
+    int sec;         // section offset (floats per point)
+    int ld;          // floats per point row
+    int col0;        // first column of the panel
+    int valid;       // valid columns (<= 128, multiple of 4)
+};
+struct NfDwWaveJob {     // one 128 x 128 product = two waves
+    int a, b;        // panel slots of the A (gradient) and B (activation) operand
+    int n_valid, k_valid;
+    int out_off, ldo;
+    int cs_off;      // >= 0: also write column sums of A (bias grads)
+};
+struct NfDwGroup {
+    NfDwPanel panel[NF_DW_MAXP];
+    NfDwWaveJob wave[4];
+};
+
+__device__ __attribute__((aligned(16))) static const float nf_dw_zero16[4] = {0.f, 0.f, 0.f, 0.f};
+
+template <int N> __device__ __forceinline__ void nf_dw_wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+
+template <int MODEL>
+__global__ void __launch_bounds__(64 * NF_DW_WAVES, 1)
+k_dw_gemm_lds(const NfDwGroup* __restrict__ groups, int slab_floats, const float* __restrict__ dz, const float* __restrict__ d_raw,
+              const float* __restrict__ saved, int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) char lds[NF_DW_STAGES * NF_DW_STAGE_BYTES];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int g = lane >> 4, i = lane & 15;
+    const NfDwGroup& grp = groups[blockIdx.x];
+    const NfDwWaveJob job = grp.wave[wave >> 1];
+    const int half = wave & 1;                        // B columns 64 half .. + 63 of the product
+    const bool active = 64 * half < job.k_valid;      // wave-uniform: an idle wave only moves data
+    const bool want_cs = job.cs_off >= 0 && half == 0;
+    const int slice = blockIdx.y;
+    const int64_t p_begin = (int64_t)slice * pts_per_slice;
+    int64_t p_end = p_begin + pts_per_slice;
+    if (p_end > n_points) p_end = n_points;
+    const int n_rows = (int)(p_end > p_begin ? p_end - p_begin : 0);
+    const int n_full = n_rows >> 4;                   // whole 16-point chunks (block-uniform): the pipelined loop
+    float* out = slabs + (int64_t)slice * slab_floats + job.out_off;
+
+    // ---- DMA: piece (panel s, j) moves rows 2 j, 2 j + 1 of the chunk; wave w issues piece j = w of every panel.
+    // Every lane keeps its 6 source pointers and advances them by one chunk per issue.  Lanes past a narrow panel's `valid`
+    // columns re-read its last valid piece: those columns only feed output tiles nobody stores.
+    const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
+    const char* src[NF_DW_MAXP];               // source of the NEXT chunk to issue
+    int step_b[NF_DW_MAXP];                    // bytes per chunk (wave-uniform)
+#pragma unroll
+    for (int s = 0; s < NF_DW_MAXP; ++s) {
+        const NfDwPanel pn = grp.panel[s];
+        const bool on = pn.kind >= 0;
+        const float* base = pn.kind == 1 ? d_raw : ((pn.kind == 0 ? dz : saved) + (int64_t)pn.sec * n_points);
+        const int ld = on ? pn.ld : 0;
+        const int col = on ? (dma_col < pn.valid ? dma_col : pn.valid - 4) : 0;
+        step_b[s] = 64 * ld;
+        src[s] = on ? reinterpret_cast<const char*>(base + (p_begin + 2 * wave + dma_row) * ld + pn.col0 + col)
+                    : reinterpret_cast<const char*>(nf_dw_zero16);
+    }
+    // issue this wave's piece of panel s of the next chunk into `stage`; with advance = false the pointer stays (dummy issues
+    // past the last chunk re-read it: harmless, and the counted waits stay uniform)
+    auto issue_piece = [&](int s, int stage, bool advance) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[s],
+                                         (__attribute__((address_space(3))) void*)(lds + stage * NF_DW_STAGE_BYTES + wave * 1024 + s * NF_DW_PANEL_BYTES),
+                                         16, 0, 0);
+        src[s] += advance ? step_b[s] : 0;
+    };
+    auto issue = [&](int stage, bool advance) {
+#pragma unroll
+        for (int s = 0; s < NF_DW_MAXP; ++s) issue_piece(s, stage, advance);
+    };
+    constexpr int NDMA = NF_DW_MAXP;           // per wave and chunk
+
+    // ---- operands: lane (g, i) reads 4 consecutive features 4 i .. + 3 (+ 64 q) of point 4 r + g; component t of that float4 is
+    // the lane's operand of MFMA tile (q, t), whose 16 rows are the features 64 q + 4 i' + t (as in k_dw_gemm).
+    const int lane_off = g * 512 + i * 16;
+    f32x4 a0[4][2], b0[4];
+    auto read_step = [&](int stage, int r) {
+        const char* sa = lds + stage * NF_DW_STAGE_BYTES + job.a * NF_DW_PANEL_BYTES + lane_off;
+        const char* sb = lds + stage * NF_DW_STAGE_BYTES + job.b * NF_DW_PANEL_BYTES + half * 256 + lane_off;
+        a0[r][0] = *reinterpret_cast<const f32x4*>(sa + r * 2048);
+        a0[r][1] = *reinterpret_cast<const f32x4*>(sa + r * 2048 + 256);
+        b0[r] = *reinterpret_cast<const f32x4*>(sb + r * 2048);
+    };
+
+    f32x4 acc[8][4];                        // [4 sb + t][t']: rows 64 sb + 4 (4 g + r') + t, columns 64 half + 4 c + t'
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) acc[nt][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 cs[2];
+    cs[0] = cs[1] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    auto mma_step = [&](int r) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+                acc[nt][kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[r][nt >> 2][nt & 3], b0[r][kt], acc[nt][kt], 0, 0, 0);
+    };
+
+    // ---- pipeline over the whole chunks, three LDS stages.  At the top of iteration c: the registers hold chunk c, chunk c + 1
+    // has landed in LDS, chunk c + 2 is in flight, and the stage of chunk c is free (every wave's reads of it completed before the
+    // barrier).  Under its 128 MFMAs the iteration issues the DMA of chunk c + 3 into that free stage and, as soon as the 32 MFMAs
+    // of a 4-point step have issued, refills the step's 3 operand registers from chunk c + 1.
+    if (n_full > 0) {
+        issue(0, n_full > 1);
+        issue(1, n_full > 2);
+        issue(2, n_full > 3);
+        nf_dw_wait_vm_lgkm0<2 * NDMA>();                             // my pieces of chunk 0 have landed
+        __builtin_amdgcn_s_barrier();                                // ... and everybody's
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) read_step(0, r);                 // (idle halves too: keeps the prologue uniform)
+        nf_dw_wait_vm_lgkm0<NDMA>();                                 // chunk 1 landed; chunk 0 is in my registers
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        int st = 0;                                                  // stage of the chunk in the registers
+#pragma unroll 1
+        for (int c = 0; c < n_full; ++c) {
+            const int s1 = st == NF_DW_STAGES - 1 ? 0 : st + 1;
+            const bool adv = c + 4 < n_full;
+            if (active) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (want_cs) {   // column sums of this chunk's A operands (bias gradients), before the refills overwrite them
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { cs[0] += a0[r][0]; cs[1] += a0[r][1]; }
+                }
+                // Four steps, fenced from one another (sched_barrier) so that the requested order is local and exact: 16 MFMAs,
+                // a DMA piece of chunk c + 3 (-> the stage chunk c left), 16 MFMAs, a second piece, then the refill of the step's
+                // 3 operand registers from chunk c + 1 -- issued right behind the MFMAs that read them.
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    mma_step(r);
+                    if (r < 3) { issue_piece(2 * r, st, adv); issue_piece(2 * r + 1, st, adv); }
+                    read_step(s1, r);                                // (after the last chunk: reads a stage nobody uses)
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    if (r < 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+                    if (r < 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                issue(st, adv);                                      // an idle half only moves data
+            }
+            nf_dw_wait_vm_lgkm0<NDMA>();                             // chunk c + 2 landed (c + 3 may still fly); my refills are in
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            st = s1;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // no DMA may outlive the workgroup's LDS
+    }
+    bool a_ok[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) a_ok[q] = 64 * q + 4 * i < job.n_valid;
+    const bool b_ok = 64 * half + 4 * i < job.k_valid;
+    if (n_rows & 15) {   // the partial chunk the last slice can end with: straight from memory, rows past the end read 0
+        const NfDwPanel pa = grp.panel[job.a], pb = grp.panel[job.b];
+        const float* A = (pa.kind == 1 ? d_raw : dz + (int64_t)pa.sec * n_points) + pa.col0;
+        const float* B = saved + (int64_t)pb.sec * n_points + pb.col0 + 64 * half;
+        const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t row = p_begin + 16 * n_full + 4 * r + g;
+            const bool rv = row < p_end;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) a0[r][q] = (rv && a_ok[q]) ? *reinterpret_cast<const f32x4*>(A + row * pa.ld + 64 * q + 4 * i) : zero4;
+            b0[r] = (rv && b_ok) ? *reinterpret_cast<const f32x4*>(B + row * pb.ld + 4 * i) : zero4;
+        }
+        if (want_cs) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { cs[0] += a0[r][0]; cs[1] += a0[r][1]; }
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) mma_step(r);
+        }
+    }
+
+    // D of tile (nt = 4 sb + t, t'): lane (g, c = i), reg r' -> row n = 64 sb + 4 (4 g + r') + t, column k = 64 half + 4 c + t'.
+    // For fixed (nt, r') a lane holds 4 consecutive k: one 16-byte store.
+    if (active) {
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nrow = 64 * (nt >> 2) + 4 * (4 * g + r) + (nt & 3);
+                if (nrow < job.n_valid && b_ok)
+                    *reinterpret_cast<f32x4*>(out + (int64_t)nrow * job.ldo + 64 * half + 4 * i) =
+                        (f32x4){acc[nt][0][r], acc[nt][1][r], acc[nt][2][r], acc[nt][3][r]};
+            }
+    }
+    if (want_cs) {
+        float* cso = slabs + (int64_t)slice * slab_floats + job.cs_off;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            f32x4 v = cs[q];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { v[t] += __shfl_xor(v[t], 16, 64); v[t] += __shfl_xor(v[t], 32, 64); }
+            if (g == 0 && a_ok[q]) *reinterpret_cast<f32x4*>(cso + 64 * q + 4 * i) = v;
+        }
+    }
+}
+
 // B3, first half: sum the per-slice slabs in a fixed order (deterministic).  16 bytes per thread, four independent partial
 // sums (slices k = 0, 1, 2, 3 mod 4) so that the loads of consecutive slices overlap; slab_floats is a multiple of 4.
 template <int MODEL>
@@ -144,6 +368,32 @@ static inline void nf_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_
     *n_slices = (int)((n_points + pps - 1) / pps);
 }
 
+// per-device copy of a group table (shared-panel kernel)
+struct NfDwGroupTable {
+    std::mutex mutex;
+    NfDwGroup* dev[64] = {nullptr};
+    template <class Build>
+    int get(int n_groups, Build build, const NfDwGroup** out) {
+        int d = 0;
+        hipError_t e = hipGetDevice(&d);
+        if (e != hipSuccess) return (int)e;
+        if (d < 0 || d >= 64) return NF_EINVAL;
+        std::lock_guard<std::mutex> lock(mutex);
+        if (!dev[d]) {
+            std::vector<NfDwGroup> host(n_groups);
+            build(host.data());
+            NfDwGroup* p = nullptr;
+            e = hipMalloc(&p, host.size() * sizeof(NfDwGroup));
+            if (e != hipSuccess) return (int)e;
+            e = hipMemcpy(p, host.data(), host.size() * sizeof(NfDwGroup), hipMemcpyHostToDevice);
+            if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
+            dev[d] = p;
+        }
+        *out = dev[d];
+        return 0;
+    }
+};
+
 // per-device copy of a job table
 struct NfDwJobTable {
     std::mutex mutex;
@@ -169,6 +419,41 @@ struct NfDwJobTable {
         return 0;
     }
 };
+
+// host-only self-test of a shared-panel group table: as nf_check_dw_jobs, plus every wave's tile shape must equal its panels'
+static inline int nf_check_dw_groups(const NfDwGroup* groups, int n_groups, int slab_floats, long expected_entries) {
+    std::vector<unsigned char> hits((size_t)slab_floats, 0);
+    long total = 0;
+    for (int gi = 0; gi < n_groups; ++gi) {
+        const NfDwGroup& gr = groups[gi];
+        for (int s = 0; s < NF_DW_MAXP; ++s) {
+            const NfDwPanel& pn = gr.panel[s];
+            if (pn.kind < 0) continue;
+            if (pn.kind > 2 || pn.valid < 4 || pn.valid > 128 || (pn.valid & 3) || (pn.col0 & 3) || (pn.ld & 3) || pn.col0 + pn.valid > pn.ld) return -10;
+        }
+        for (int w = 0; w < 4; ++w) {
+            const NfDwWaveJob& j = gr.wave[w];
+            if (j.a < 0 || j.a >= NF_DW_MAXP || j.b < 0 || j.b >= NF_DW_MAXP) return -11;
+            const NfDwPanel &pa = gr.panel[j.a], &pb = gr.panel[j.b];
+            if (pa.kind < 0 || pa.kind > 1 || pb.kind != 2) return -12;
+            if (j.n_valid != pa.valid || j.k_valid != pb.valid) return -13;
+            for (int r = 0; r < j.n_valid; ++r)
+                for (int c = 0; c < j.k_valid; ++c) {
+                    const long e = (long)j.out_off + (long)r * j.ldo + c;
+                    if (e < 0 || e >= slab_floats) return -2;
+                    if (hits[e]++) return -3;
+                    ++total;
+                }
+            if (j.cs_off >= 0)
+                for (int r = 0; r < j.n_valid; ++r) {
+                    if (j.cs_off + r >= slab_floats) return -4;
+                    if (hits[j.cs_off + r]++) return -5;
+                    ++total;
+                }
+        }
+    }
+    return total == expected_entries ? 0 : -6;
+}
 
 // host-only self-test of an exact-f32 job table: no slab entry written twice, `expected_entries` entries written in total
 static inline int nf_check_dw_jobs(const NfDwJob* jobs, int n_jobs, int slab_floats, long expected_entries) {
