@@ -260,6 +260,8 @@ static void nf_build_dw_groups(NfDwGroup* gr) {
     auto fresh = [&]() -> NfDwGroup& {
         NfDwGroup& g = gr[n++];
         for (auto& p : g.panel) p = off;
+        g.share = 2;
+        g.n_slices = g.pts_per_slice = 0;
         return g;
     };
     auto job = [](const NfDwGroup& g, int a, int b, int out_off, int ldo, int cs) {
@@ -289,6 +291,7 @@ static void nf_build_dw_groups(NfDwGroup* gr) {
             g.panel[2 + h] = NfDwPanel{0, Z_L3, 256, 128 * h, 128};
         }
         g.panel[4] = NfDwPanel{2, S_PE, 64, 0, 64};
+        g.share = 1;                                                 // second halves idle: half the MFMAs per point
         for (int nb = 0; nb < 2; ++nb) {
             g.wave[nb] = job(g, nb, 4, G_L0 + 128 * nb * 64, 64, CS_L0 + 128 * nb);
             g.wave[2 + nb] = job(g, 2 + nb, 4, G_L3A + 128 * nb * 64, 64, CS_L0 + 768 + 128 * nb);
@@ -414,11 +417,14 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     nf_bwd_plan(n_points, &pps, &ns);
     nfb_dw_plan(0, n_points, &pps, &ns_b);
     if (ns_b > ns) ns = ns_b;
+    NfDwGroup groups[NF_DW_GROUPS];
+    nf_build_dw_groups(groups);
+    ns_b = nf_dw_plan_groups(groups, NF_DW_GROUPS, n_points);
+    if (ns_b > ns) ns = ns_b;
     return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS + 16;      // + max |gradient| per dz section (fp16 kernels)
 }
 
 static NfDwJobTable g_paper_jobs;
-static NfDwGroupTable g_paper_groups;
 
 // defined in nf_mlp_bf16_bwd.hip / nf_mlp_f16_bwd.hip
 int nfb_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
@@ -446,8 +452,15 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     const int rcj = g_paper_jobs.get(NF_DW_JOBS, nf_build_dw_jobs, &jobs);
     if (rcj) return rcj;
     int64_t pps; int ns;
+    NfDwGroupSet gset;
     if (split_dw) nfb_dw_plan(0, n_points, &pps, &ns);
-    else nf_bwd_plan(n_points, &pps, &ns);
+    else if (nf_legacy_train()) nf_bwd_plan(n_points, &pps, &ns);
+    else {
+        nf_build_dw_groups(gset.g);
+        for (int k = 0; k <= NF_DW_MAX_GROUPS; ++k) gset.first_block[k] = 0x7fffffff;
+        ns = nf_dw_plan_groups(gset.g, NF_DW_GROUPS, n_points, gset.first_block);
+        pps = 0;
+    }
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
@@ -484,11 +497,8 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
             hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
                                saved, n_points, pps, slabs);
         } else {
-            const NfDwGroup* groups = nullptr;
-            const int rcg = g_paper_groups.get(NF_DW_GROUPS, nf_build_dw_groups, &groups);
-            if (rcg) return rcg;
-            hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(NF_DW_GROUPS, ns), dim3(64 * NF_DW_WAVES), 0, s, groups, (int)SLAB_FLOATS, dz, d_raw, saved,
-                               n_points, pps, slabs);
+            hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(gset.first_block[NF_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz, d_raw, saved,
+                               n_points, slabs);
         }
     }
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);

@@ -45,11 +45,69 @@ __device__ __forceinline__ void nf_mma_from_regs(f32x4 (&acc)[NT][16], const f32
     }
 }
 
-// K chunks whose B fragments come from the wave's LDS slab; weights are register double-buffered one
-// chunk ahead.  nch must be even.
+// K chunks whose B fragments come from the wave's LDS slab -- the TRAINING kernels' loop.  Explicit software pipeline, one
+// half-iteration = one chunk:
+//   half 1:  MFMAs of chunk ni   (weights wa, fragment b0)  |  loads of chunk ni + 1 -> wb,  ds_read of its fragment -> b1
+//   half 2:  MFMAs of chunk ni+1 (weights wb, fragment b1)  |  loads of chunk ni + 2 -> wa,  ds_read of its fragment -> b0
+// Every weight fragment is requested one chunk (128 MFMAs, 4096 cycles) before its MFMAs and every B fragment one chunk before
+// its use; the sched_group_barrier sequence asks for one load per 8 MFMAs (one output tile), with the slab copy's stores and LDS
+// reads (`Side`) at fixed places among them.  The loads past the last chunk re-read it (harmless): no branch, one wait schedule.
+// nch must be even.
+struct NfNoSide {
+    __device__ __forceinline__ void half1(int) const {}
+    __device__ __forceinline__ void half2(int) const {}
+    static constexpr int N_STORE = 0, N_READ = 0;
+};
+
+template <int NT, int NO, class Side>
+__device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4,
+                                                     int lane, Side& side) {
+    const int g = lane >> 4, c = lane & 15;
+    f32x4 wa[NO], wb[NO], b0[NT], b1[NT];
+    nf_load_w<NT, NO>(wa, wsec, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) b0[t] = act4[nf_act_idx4(16 * t + c, g)];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 1
+    for (int ni = 0; ni < nch; ni += 2) {
+        // ---- half 1
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b1[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
+        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
+        nf_mma_chunk<NT, NO>(acc, wa, b0);
+        side.half1(ni >> 1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);                              // the next fragment's LDS reads first
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);                      // one output tile: 4 NT MFMAs
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                           // one weight load of the next chunk
+            if (Side::N_STORE > 0 && no % (NO / Side::N_STORE > 0 ? NO / Side::N_STORE : 1) == 0 && no / (NO / Side::N_STORE > 0 ? NO / Side::N_STORE : 1) < Side::N_STORE)
+                __builtin_amdgcn_sched_group_barrier(0x040, 1, 0);                       // (training: one store of the slab copy)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- half 2
+        const int nx = ni + 2 < nch ? ni + 2 : ni;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b0[t] = act4[nf_act_idx4(16 * t + c, 4 * nx + g)];
+        side.half2(ni >> 1);
+        nf_load_w<NT, NO>(wa, wsec + (size_t)nx * NO * 64, lane);
+        nf_mma_chunk<NT, NO>(acc, wb, b1);
+        __builtin_amdgcn_sched_group_barrier(0x100, NT + Side::N_READ, 0);
+#pragma unroll
+        for (int no = 0; no < NO; ++no) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Inference kernels: the plain loop, weights register double-buffered one chunk ahead, scheduled by the compiler.  Measured on
+// the same box against the explicit pipeline above (profiles/r03_mlp_f32_pmc.md): 94.03 vs 94.74 ms per fine launch -- the
+// pipeline removes s_waitcnt time (4.9 % -> 3.1 % of the wave cycles) but its per-tile load / wait pairs cost as many issue slots,
+// so the inference path keeps this form and the training kernels (which need the Side hooks) use the pipeline.  nch must be even.
 template <int NT, int NO>
-__device__ __forceinline__ void nf_mma_from_lds(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch,
-                                                const f32x4* act4, int lane) {
+__device__ __forceinline__ void nf_mma_from_lds(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4, int lane) {
     const int g = lane >> 4, c = lane & 15;
     f32x4 wa[NO], wb[NO];
     nf_load_w<NT, NO>(wa, wsec, lane);
@@ -194,37 +252,55 @@ __device__ __forceinline__ NfSlabCopy nf_slab_copy(float* base, int sec, int wid
     return c;
 }
 
-// copy instruction `inst` of a slab whose rows are W4 float4 wide (64 / W4 rows per instruction)
+// copy instruction `inst` of a slab whose rows are W4 float4 wide (64 / W4 rows per instruction): LDS read and global store halves
 template <int W4>
-__device__ __forceinline__ void nf_copy_rows(const f32x4* act4, const NfSlabCopy& cp, int inst, int lane) {
+__device__ __forceinline__ f32x4 nf_copy_read(const f32x4* act4, int inst, int lane) {
     constexpr int RPI = 64 / W4;
     const int p = inst * RPI + lane / W4, q = lane % W4;
-    const f32x4 v = act4[nf_act_idx4(p, q)];
+    return act4[nf_act_idx4(p, q)];
+}
+template <int W4>
+__device__ __forceinline__ void nf_copy_write(const f32x4 v, const NfSlabCopy& cp, int inst, int lane) {
+    constexpr int RPI = 64 / W4;
+    const int p = inst * RPI + lane / W4, q = lane % W4;
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, 0);
+}
+template <int W4>
+__device__ __forceinline__ void nf_copy_rows(const f32x4* act4, const NfSlabCopy& cp, int inst, int lane) {
+    nf_copy_write<W4>(nf_copy_read<W4>(act4, inst, lane), cp, inst, lane);
 }
 
 // nf_mma_from_lds + the deferred copy of the slab it reads (the previous layer's output, W4 float4 per row): PER copy
-// instructions per loop iteration; (nch / 2) * PER must equal the 16 NT * W4 / 64 instructions the slab takes.
+// instructions per loop iteration; (nch / 2) * PER must equal the 16 NT * W4 / 64 instructions the slab takes.  The rows of
+// iteration k are read from LDS during iteration k - 1 (PER staging registers) and stored under the first chunk's MFMAs.
+template <int W4, int PER>
+struct NfCopySide {
+    const f32x4* act4;
+    NfSlabCopy cp;
+    int lane, n_it;
+    f32x4 cv[PER];
+    static constexpr int N_STORE = PER, N_READ = PER;
+    __device__ __forceinline__ void prime() {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, k, lane);
+    }
+    __device__ __forceinline__ void half1(int it) const {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) nf_copy_write<W4>(cv[k], cp, it * PER + k, lane);
+    }
+    __device__ __forceinline__ void half2(int it) {                      // past the last iteration: re-read its rows (unused)
+        const int nx = it + 1 < n_it ? it + 1 : it;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, nx * PER + k, lane);
+    }
+};
+
 template <int NT, int NO, int W4, int PER>
 __device__ __forceinline__ void nf_mma_from_lds_copy(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4,
                                                      int lane, const NfSlabCopy& cp) {
-    const int g = lane >> 4, c = lane & 15;
-    f32x4 wa[NO], wb[NO];
-    nf_load_w<NT, NO>(wa, wsec, lane);
-#pragma unroll 1
-    for (int ni = 0; ni < nch; ni += 2) {
-        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
-        f32x4 b[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
-        nf_mma_chunk<NT, NO>(acc, wa, b);
-#pragma unroll
-        for (int k = 0; k < PER; ++k) nf_copy_rows<W4>(act4, cp, (ni >> 1) * PER + k, lane);
-        if (ni + 2 < nch) nf_load_w<NT, NO>(wa, wsec + (size_t)(ni + 2) * NO * 64, lane);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
-        nf_mma_chunk<NT, NO>(acc, wb, b);
-    }
+    NfCopySide<W4, PER> side{act4, cp, lane, nch >> 1, {}};
+    side.prime();
+    nf_mma_from_lds_side<NT, NO>(acc, wsec, nch, act4, lane, side);
 }
 
 // ReLU bit masks of the exact-f32 kernels: section nfl::S_MASK of `saved`, [9 layers][ceil(n / 16) point tiles][64 lanes][2 dwords];

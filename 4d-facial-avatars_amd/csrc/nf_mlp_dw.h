@@ -151,7 +151,43 @@ struct NfDwWaveJob {     // one 128 x 128 product = two waves
 struct NfDwGroup {
     NfDwPanel panel[NF_DW_MAXP];
     NfDwWaveJob wave[4];
+    int share;       // relative cost of the group in half-units: 2 = four full products, 1 = products whose second half is idle (PE)
+    int n_slices;    // filled by nf_dw_plan_groups for the launch at hand
+    int pts_per_slice;
 };
+
+#define NF_DW_MAX_GROUPS 9
+struct NfDwGroupSet {                                         // passed by value: the slice plan changes with the launch size
+    NfDwGroup g[NF_DW_MAX_GROUPS];
+    int first_block[NF_DW_MAX_GROUPS + 1];                    // 1-D grid: blocks first_block[i] .. first_block[i + 1] - 1 are the slices of group i
+};
+
+// Slices per group: one workgroup per CU and all of them busy for the same time -- a group's slice count is proportional to its
+// cost, and the grid holds exactly the (group, slice) pairs that exist, at most n_cu of them: workgroups are dealt to the eight XCDs
+// round-robin, so a 2-D grid padded with empty blocks put 33 live workgroups on some XCDs' 32 CUs and doubled the kernel time.
+// Returns the largest slice count (= number of slabs the reduction sums).
+static inline int nf_dw_plan_groups(NfDwGroup* g, int n_groups, int64_t n_points, int* first_block = nullptr, int n_cu = 256) {
+    int shares = 0;
+    for (int i = 0; i < n_groups; ++i) shares += g[i].share;
+    int unit = (2 * n_cu) / shares;                                  // slices of a share-2 group
+    if (unit < 1) unit = 1;
+    int most = 1;
+    for (int i = 0; i < n_groups; ++i) {
+        int ns = unit * g[i].share / 2;
+        if (ns < 1) ns = 1;
+        int64_t pps = (n_points + ns - 1) / ns;
+        pps = (pps + 15) / 16 * 16;
+        if (pps < 1024) pps = 1024;
+        g[i].pts_per_slice = (int)pps;
+        g[i].n_slices = (int)((n_points + pps - 1) / pps);
+        if (g[i].n_slices > most) most = g[i].n_slices;
+    }
+    if (first_block) {
+        first_block[0] = 0;
+        for (int i = 0; i < n_groups; ++i) first_block[i + 1] = first_block[i] + g[i].n_slices;
+    }
+    return most;
+}
 
 __device__ __attribute__((aligned(16))) static const float nf_dw_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
@@ -159,17 +195,23 @@ template <int N> __device__ __forceinline__ void nf_dw_wait_vm_lgkm0() { asm vol
 
 template <int MODEL>
 __global__ void __launch_bounds__(64 * NF_DW_WAVES, 1)
-k_dw_gemm_lds(const NfDwGroup* __restrict__ groups, int slab_floats, const float* __restrict__ dz, const float* __restrict__ d_raw,
-              const float* __restrict__ saved, int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs) {
+k_dw_gemm_lds(NfDwGroupSet gs, int slab_floats, const float* __restrict__ dz, const float* __restrict__ d_raw,
+              const float* __restrict__ saved, int64_t n_points, float* __restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) char lds[NF_DW_STAGES * NF_DW_STAGE_BYTES];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int g = lane >> 4, i = lane & 15;
-    const NfDwGroup& grp = groups[blockIdx.x];
-    const NfDwWaveJob job = grp.wave[wave >> 1];
-    const int half = wave & 1;                        // B columns 64 half .. + 63 of the product
+    int gi = 0;
+#pragma unroll
+    for (int k = 1; k < NF_DW_MAX_GROUPS; ++k) gi += (int)blockIdx.x >= gs.first_block[k] ? 1 : 0;     // (first_block is non-decreasing)
+    const NfDwGroup& grp = gs.g[gi];
+    const int slice = (int)blockIdx.x - gs.first_block[gi];
+    const int64_t pts_per_slice = grp.pts_per_slice;
+    // waves w and w + 4 share a SIMD (waves are dealt round-robin over the four SIMDs): the two halves of one product, so a
+    // product with an idle second half costs its SIMD half the MFMAs instead of leaving another SIMD empty
+    const NfDwWaveJob job = grp.wave[wave & 3];
+    const int half = wave >> 2;                       // B columns 64 half .. + 63 of the product
     const bool active = 64 * half < job.k_valid;      // wave-uniform: an idle wave only moves data
     const bool want_cs = job.cs_off >= 0 && half == 0;
-    const int slice = blockIdx.y;
     const int64_t p_begin = (int64_t)slice * pts_per_slice;
     int64_t p_end = p_begin + pts_per_slice;
     if (p_end > n_points) p_end = n_points;
@@ -368,32 +410,6 @@ static inline void nf_bwd_plan(int64_t n_points, int64_t* pts_per_slice, int* n_
     *n_slices = (int)((n_points + pps - 1) / pps);
 }
 
-// per-device copy of a group table (shared-panel kernel)
-struct NfDwGroupTable {
-    std::mutex mutex;
-    NfDwGroup* dev[64] = {nullptr};
-    template <class Build>
-    int get(int n_groups, Build build, const NfDwGroup** out) {
-        int d = 0;
-        hipError_t e = hipGetDevice(&d);
-        if (e != hipSuccess) return (int)e;
-        if (d < 0 || d >= 64) return NF_EINVAL;
-        std::lock_guard<std::mutex> lock(mutex);
-        if (!dev[d]) {
-            std::vector<NfDwGroup> host(n_groups);
-            build(host.data());
-            NfDwGroup* p = nullptr;
-            e = hipMalloc(&p, host.size() * sizeof(NfDwGroup));
-            if (e != hipSuccess) return (int)e;
-            e = hipMemcpy(p, host.data(), host.size() * sizeof(NfDwGroup), hipMemcpyHostToDevice);
-            if (e != hipSuccess) { (void)hipFree(p); return (int)e; }
-            dev[d] = p;
-        }
-        *out = dev[d];
-        return 0;
-    }
-};
-
 // per-device copy of a job table
 struct NfDwJobTable {
     std::mutex mutex;
@@ -426,6 +442,7 @@ static inline int nf_check_dw_groups(const NfDwGroup* groups, int n_groups, int 
     long total = 0;
     for (int gi = 0; gi < n_groups; ++gi) {
         const NfDwGroup& gr = groups[gi];
+        if (gr.share < 1 || gr.share > 2) return -14;
         for (int s = 0; s < NF_DW_MAXP; ++s) {
             const NfDwPanel& pn = gr.panel[s];
             if (pn.kind < 0) continue;

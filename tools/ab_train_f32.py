@@ -1,8 +1,8 @@
 """A/B of the exact-f32 training kernels of the paper model: round-3 (line-wide deferred saves + ReLU bit masks in the forward
 and the dX chain, shared-panel weight-gradient kernel) against round-2 (nf_debug_legacy_train(1)), same inputs, same process.
 
-Checks that raw, every saved section, every dZ section and the 26 gradients + d latent are BIT-IDENTICAL between the two, and
-times the forward-with-saves call and the backward call (chain + dW + reduce + unpack) with HIP events on torch's stream.
+Checks that raw, every saved section and every dZ section are BIT-IDENTICAL between the two and that the 26 gradients + d latent
+agree to rounding (the weight-gradient kernel slices the points differently, so the slab sums associate differently), and times the forward-with-saves call and the backward call (chain + dW + reduce + unpack) with HIP events on torch's stream.
 
     python tools/ab_train_f32.py [--rays 2048] [--samples 64 128] [--iters 20] [--json out.json]
 """
@@ -85,10 +85,12 @@ def main():
             t_b = timed(bwd)
             res[legacy] = dict(raw=raw.clone(), saved=saved[:2256 * n].clone(), dz=ws[:2176 * n].clone(), flat=flat.clone(), t_f=t_f, t_b=t_b)
         dbg(0)
-        same = {k: bool(torch.equal(res[0][k], res[1][k])) for k in ("raw", "saved", "dz", "flat")}
+        same = {k: bool(torch.equal(res[0][k], res[1][k])) for k in ("raw", "saved", "dz")}
         worst = {k: float((res[0][k] - res[1][k]).abs().max()) for k in ("raw", "saved", "dz", "flat")}
+        grad_rel = float((res[0]["flat"].double() - res[1]["flat"].double()).norm() / res[1]["flat"].double().norm())
+        same["grads_to_rounding"] = grad_rel < 2e-6
         key = f"{n_rays}x{n_s}"
-        out[key] = dict(points=n, bit_identical=same, max_abs_diff=worst,
+        out[key] = dict(points=n, bit_identical=same, max_abs_diff=worst, grads_rel_l2=grad_rel,
                         fwd_save_ms=dict(r02=res[1]["t_f"], r03=res[0]["t_f"]), bwd_ms=dict(r02=res[1]["t_b"], r03=res[0]["t_b"]))
         print(key, json.dumps(out[key]))
         del res
@@ -97,7 +99,7 @@ def main():
         with open(args.json, "w") as f:
             json.dump(out, f, indent=1)
     ok = all(all(v["bit_identical"].values()) for v in out.values())
-    print("A/B", "OK: bit-identical" if ok else "MISMATCH")
+    print("A/B", "OK: forward / dZ bit-identical, gradients equal to rounding" if ok else "MISMATCH")
     return 0 if ok else 1
 
 

@@ -16,6 +16,8 @@ for n_rays, S in ((65536, 192), (65536, 64)):
                      ("f16x3", lambda: ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro_, rd_, z))):
         if name == "f32" and os.environ.get("TIME_MLP_SKIP_F32"):
             continue
+        if name != "f32" and os.environ.get("TIME_MLP_ONLY_F32"):
+            continue
         fn(); fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
