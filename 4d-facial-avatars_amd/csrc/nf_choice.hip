@@ -7,20 +7,23 @@
 // e_i = -log(1 - u_i).  The n smallest keys are found by an exact three-level radix select on the 32 key bits (12 + 12 + 8;
 // positive floats order like their bit patterns): each level is one launch that histograms the digit of the keys that match the
 // prefix found so far (LDS histogram per workgroup, merged with global atomics), and the LAST workgroup to finish scans the
-// 4096 bins, extends the prefix and clears the histogram for the next level.  A fourth launch emits the indices: every key below
-// the threshold, plus as many keys equal to it as are still missing (slots come from an atomic counter), and a one-workgroup
-// bitonic sort puts them in ascending order, so that a seed reproduces the batch element for element (the order of the rays
-// decides the summation order of the gradients downstream).  HBM-bound: 4 passes over 8 bytes per item (2 MB per pass for a
+// 4096 bins, extends the prefix and clears the histogram for the next level.  A fourth launch emits the indices of every key below
+// the threshold (slots come from an atomic counter) and collects the items whose key EQUALS it; a one-workgroup kernel then takes
+// as many of those ties as are still missing -- the ones with the LOWEST indices, not the first to arrive (torch.rand has 24
+// random bits: on a 512 x 512 frame the threshold key is shared in ~1.5 % of the draws) -- and a one-workgroup bitonic sort puts the
+// batch in ascending order, so that a seed reproduces the batch element for element (the order of the rays decides the
+// summation order of the gradients downstream).  HBM-bound: 4 passes over 8 bytes per item (2 MB per pass for a
 // 512 x 512 frame, L2-resident).
 #include "nf_common.h"
 
 #define NF_CHOICE_BINS 4096
+#define NF_CHOICE_MAX_TIES 1024   // tie candidates kept for the deterministic tie-break (more than that: the first to arrive)
 struct NfChoiceState {            // workspace header (uint32 words): zeroed by the host-side memset before the first level
     unsigned done;                // workgroups that have flushed their histogram (reset by the scanning workgroup)
     unsigned prefix;              // key bits fixed so far
     unsigned remaining;           // how many keys of the current prefix class are still wanted
     unsigned emitted;             // select pass: slots handed out to keys below the threshold
-    unsigned ties;                // select pass: keys equal to the threshold taken so far
+    unsigned ties;                // select pass: keys equal to the threshold seen so far
     unsigned short_of;            // != 0: fewer than n items with a positive weight (np.random.choice raises ValueError there)
     unsigned pad[2];
 };
@@ -102,17 +105,31 @@ __global__ void __launch_bounds__(256) k_choice_level(const float* __restrict__ 
 }
 
 __global__ void __launch_bounds__(256) k_choice_select(const float* __restrict__ w, const float* __restrict__ u, int64_t n_items, int n_select,
-                                                       NfChoiceState* __restrict__ st, int64_t* __restrict__ idx_out) {
-    const unsigned thr = st->prefix, ties_wanted = st->remaining;
+                                                       NfChoiceState* __restrict__ st, int64_t* __restrict__ tie_buf, int64_t* __restrict__ idx_out) {
+    const unsigned thr = st->prefix;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
         const unsigned k = nf_choice_key(w, u, i);
         if (k == 0x7f800000u) continue;                             // weight 0
-        bool take = k < thr;
-        if (k == thr) take = atomicAdd(&st->ties, 1u) < ties_wanted;
-        if (take) {
+        if (k < thr) {
             const unsigned slot = atomicAdd(&st->emitted, 1u);
             if (slot < (unsigned)n_select) idx_out[slot] = i;
+        } else if (k == thr) {
+            const unsigned t = atomicAdd(&st->ties, 1u);
+            if (t < NF_CHOICE_MAX_TIES) tie_buf[t] = i;
         }
+    }
+}
+
+// the `remaining` lowest-indexed ties fill the slots behind the keys below the threshold (rank by counting: the list is short)
+__global__ void __launch_bounds__(256) k_choice_ties(int n_select, const NfChoiceState* __restrict__ st, const int64_t* __restrict__ tie_buf,
+                                                     int64_t* __restrict__ idx_out) {
+    const unsigned n_t = st->ties < NF_CHOICE_MAX_TIES ? st->ties : NF_CHOICE_MAX_TIES;
+    const unsigned wanted = st->remaining, base = st->emitted;
+    for (unsigned a = threadIdx.x; a < n_t; a += 256) {
+        const int64_t mine = tie_buf[a];
+        unsigned rank = 0;
+        for (unsigned b = 0; b < n_t; ++b) rank += tie_buf[b] < mine ? 1u : 0u;
+        if (rank < wanted && base + rank < (unsigned)n_select) idx_out[base + rank] = mine;
     }
 }
 
@@ -139,7 +156,9 @@ __global__ void __launch_bounds__(1024) k_choice_sort(int64_t* __restrict__ idx,
     for (int i = threadIdx.x; i < n; i += 1024) idx[i] = (int64_t)v[i];
 }
 
-extern "C" size_t nf_weighted_choice_workspace_bytes(void) { return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned); }
+extern "C" size_t nf_weighted_choice_workspace_bytes(void) {
+    return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned) + NF_CHOICE_MAX_TIES * sizeof(int64_t);
+}
 
 extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t n_items, int n_select, int64_t* idx_out, void* workspace,
                                   size_t workspace_bytes, nf_stream_t stream) {
@@ -154,12 +173,14 @@ extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t 
     if (e != hipSuccess) return (int)e;
     NfChoiceState* st = reinterpret_cast<NfChoiceState*>(workspace);
     unsigned* hist = reinterpret_cast<unsigned*>(st + 1);
+    int64_t* tie_buf = reinterpret_cast<int64_t*>(hist + NF_CHOICE_BINS);
     const int64_t want = (n_items + 255) / 256;
     const int grid = (int)(want < 256 ? want : 256);
     hipLaunchKernelGGL(k_choice_level<0>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<1>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<2>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
-    hipLaunchKernelGGL(k_choice_select, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, idx_out);
+    hipLaunchKernelGGL(k_choice_select, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, tie_buf, idx_out);
+    hipLaunchKernelGGL(k_choice_ties, dim3(1), dim3(256), 0, s, n_select, st, tie_buf, idx_out);
     if (n_select <= NF_CHOICE_SORT_MAX)                              // larger draws stay in slot order (the Python wrapper sorts them)
         hipLaunchKernelGGL(k_choice_sort, dim3(1), dim3(1024), 0, s, idx_out, n_select);
     NF_RETURN_LAUNCH();

@@ -419,7 +419,8 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
     }
     if (t_on && tl.cs_off >= 0) {
         const float v = t_cs + __shfl_xor(t_cs, 32, 64);
-        if (h == 0 && t_fok) slab[tl.cs_off + c] = v;
+        // (lane id re-derived from mbcnt: the threadIdx-derived copy would have to live -- in the fp16 instantiation: in scratch -- across the point loop)
+        if (__lane_id() < 32 && t_fok) slab[tl.cs_off + c] = v;
     }
 }
 

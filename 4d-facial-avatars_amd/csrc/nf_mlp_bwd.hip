@@ -435,7 +435,7 @@ int nfb_launch_bwd_chain_f16(const void* packed_t, const float* saved, const flo
 // packed_t (exact f32 chain) | packed_t_bf16 (split-bf16 chain) | packed_t_f16 (split-fp16 chain + dW): exactly one non-NULL
 static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const void* packed_t_f16, bool split_dw,
                        const float* cond, const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
-                       size_t workspace_floats, float* grads, nf_stream_t stream) {
+                       size_t workspace_floats, float* grads, nf_stream_t stream, float* stage_ms = nullptr) {
     using namespace nfl;
     if (!packed || (!packed_t && !packed_t_bf16 && !packed_t_f16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 ||
         n_samples <= 0)
@@ -472,15 +472,22 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     if (grid > 0x7fffffff) return NF_EINVAL;
     e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
     if (e != hipSuccess) return (int)e;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};          // stage_ms: dX chain | weight-gradient GEMMs | reduce + unpack
+    auto mark = [&](int k) {
+        if (stage_ms && hipEventCreate(&ev[k]) == hipSuccess) (void)hipEventRecord(ev[k], s);
+    };
     if (packed_t_f16) {
         e = hipMemsetAsync(gscale, 0, 16 * sizeof(float), s);           // max |gradient| per section, filled by the chain
         if (e != hipSuccess) return (int)e;
+        mark(0);
         const int rc2 = nfb_launch_bwd_chain_f16(packed_t_f16, saved, d_raw, n_points, dz, gscale, stream);
         if (rc2) return rc2;
     } else if (packed_t_bf16) {
+        mark(0);
         const int rc2 = nfb_launch_bwd_chain_bf16(packed_t_bf16, saved, d_raw, n_points, dz, nullptr, stream);
         if (rc2) return rc2;
     } else {
+        mark(0);
         if (nf_legacy_train())
             hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
                                n_points, dz);
@@ -488,6 +495,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
             hipLaunchKernelGGL((k_paper_mlp_bwd_chain_masks<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved,
                                d_raw, n_points, dz);
     }
+    mark(1);
     if (split_dw) {
         const int rc3 = packed_t_f16 ? nfb_launch_dw_gemm_f16(0, dz, d_raw, saved, n_points, pps, ns, slabs, gscale, stream)
                                      : nfb_launch_dw_gemm_bf16(0, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
@@ -501,12 +509,36 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
                                n_points, slabs);
         }
     }
+    mark(2);
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
     NfGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];
     hipLaunchKernelGGL(k_paper_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
+    if (stage_ms) {
+        mark(3);
+        e = hipStreamSynchronize(s);
+        for (int k = 0; k < 3; ++k) {
+            stage_ms[k] = -1.0f;
+            if (e == hipSuccess && ev[k] && ev[k + 1]) (void)hipEventElapsedTime(&stage_ms[k], ev[k], ev[k + 1]);
+        }
+        for (auto& x : ev)
+            if (x) (void)hipEventDestroy(x);
+        if (e != hipSuccess) return (int)e;
+    }
     NF_RETURN_LAUNCH();
+}
+
+// Measurement hook (bench.py's per-kernel training roofline): one backward in arithmetic `precision` (0 exact f32, 1 split-bf16,
+// 2 split-fp16; packed_t_any = the matching transposed image / stream) with HIP events recorded on `stream` between its stages;
+// synchronises the stream and returns stage_ms[3] = {dX chain, weight-gradient GEMMs, slab reduction + unpack} in milliseconds.
+extern "C" int nf_paper_mlp_bwd_stage_ms(const float* packed, const void* packed_t_any, int precision, const float* cond, const float* saved,
+                                         const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
+                                         float* grads, float* stage_ms, nf_stream_t stream) {
+    if (!packed_t_any || !stage_ms || precision < 0 || precision > 2) return NF_EINVAL;
+    return nf_bwd_impl(packed, precision == 0 ? (const float*)packed_t_any : nullptr, precision == 1 ? packed_t_any : nullptr,
+                       precision == 2 ? packed_t_any : nullptr, precision != 0, cond, saved, d_raw, n_rays, n_samples, workspace,
+                       workspace_floats, grads, stream, stage_ms);
 }
 
 extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* cond, const float* saved,

@@ -21,7 +21,9 @@ from nerf import distributed as D  # noqa: E402
 def init_distributed(backend: str = "nccl"):
     """One process per GPU (torchrun / torch.distributed.run).  Returns (rank, world, device).
     backend "nccl" is RCCL over xGMI (production); "gloo" lets several ranks share one GPU (tests: the collectives are
-    staged through the host, the kernels and the launcher logic are the same)."""
+    staged through the host, the kernels and the launcher logic are the same).  NERFACE_DIST_FORCE=1: bring the process group
+    up even at world size 1 (under torch.distributed.run --nproc-per-node 1) and run every collective of the N > 1 path --
+    RCCL load, `device_id=` init, broadcast, the flat all-reduce on device memory -- on the one GPU a test box has."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -31,7 +33,7 @@ def init_distributed(backend: str = "nccl"):
         local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1 and not torch.distributed.is_initialized():
+    if (world > 1 or D.force_collectives_requested()) and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             torch.distributed.init_process_group(backend="nccl", device_id=dev)      # nccl == RCCL on ROCm
@@ -99,3 +101,54 @@ def load_background(basedir: str, H: int, W: int, device):
     im = Image.open(p)
     im.thumbnail((H, W))
     return torch.from_numpy(np.array(im).astype(np.float32) / 255.0)[..., :3].to(device)
+
+
+class ScalarLog:
+    """Rank-0 training log with the reference's TensorBoard tags (TR:203, 415-424, 518-541: train/loss, train/coarse_loss,
+    train/fine_loss, train/psnr, validation/loss, validation/coarse_loss, validation/fine_loss, validation/psnr and the
+    validation images): a torch.utils.tensorboard SummaryWriter when that imports (it needs the `tensorboard` package), else
+    the same records as JSON lines in <logdir>/scalars.jsonl.  Values may be 0-d device tensors: they are kept on the device
+    and read back together at flush(), which the trainer calls on the iterations that print anyway -- no per-iteration sync."""
+
+    def __init__(self, logdir: str):
+        self.pending = []
+        self.writer = None
+        self.path = os.path.join(logdir, "scalars.jsonl")
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self.writer = SummaryWriter(logdir)
+        except Exception:
+            self.writer = None
+
+    @property
+    def kind(self) -> str:
+        return "tensorboard" if self.writer is not None else "jsonl"
+
+    def add_scalar(self, tag: str, value, step: int) -> None:
+        self.pending.append((tag, value.detach() if torch.is_tensor(value) else float(value), int(step)))
+
+    def add_image(self, tag: str, img_chw: torch.Tensor, step: int) -> None:
+        if self.writer is not None:
+            self.writer.add_image(tag, img_chw.detach().float().clamp(0, 1).cpu(), step)
+
+    def flush(self) -> None:
+        if not self.pending:
+            return
+        tens = [v for _, v, _ in self.pending if torch.is_tensor(v)]
+        vals = iter(torch.stack([t.float().reshape(()) for t in tens]).cpu().tolist()) if tens else iter(())
+        rows = [(tag, next(vals) if torch.is_tensor(v) else v, step) for tag, v, step in self.pending]
+        self.pending = []
+        if self.writer is not None:
+            for tag, v, step in rows:
+                self.writer.add_scalar(tag, v, step)
+            self.writer.flush()
+        else:
+            import json
+            with open(self.path, "a") as f:
+                for tag, v, step in rows:
+                    f.write(json.dumps({"tag": tag, "value": v, "step": step}) + "\n")
+
+    def close(self) -> None:
+        self.flush()
+        if self.writer is not None:
+            self.writer.close()

@@ -123,8 +123,13 @@ def _main(argv=None):
         os.makedirs(os.path.join(args.savedir, "normals"), exist_ok=True)
     if args.save_error_image:
         os.makedirs(os.path.join(args.savedir, "error"), exist_ok=True)
+    # "avg time per image" (the reference's metric, EV:471-473) from HIP events around each frame's kernels: nothing in the loop
+    # waits for the GPU (PNG output and post-processing are asynchronous), so host clocks would time the launches, not the render
+    marks = []
+    t_start = time.time()
     for i in mine:
-        t0 = time.time()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
         latent = latent_codes[min(max(row, 0), latent_codes.shape[0] - 1)]
         with torch.no_grad():
@@ -146,11 +151,14 @@ def _main(argv=None):
         if args.save_error_image:
             gt = images[i].to(dev)[..., :3].reshape(H, W, 3)
             writer.submit(jet_u8(torch.linalg.norm(gt - rgb[..., :3], dim=-1)), os.path.join(args.savedir, "error", f"{i:04d}.png"))
-        times.append(time.time() - t0)
+        ev1.record()
+        marks.append((ev0, ev1))
     torch.cuda.synchronize()
     writer.close()
+    times = [a.elapsed_time(b) * 1e-3 for a, b in marks]
     if times:
-        print(f"[rank {rank}] rendered {len(times)} of {n} frames, avg time per image: {sum(times) / len(times):.3f} s")
+        print(f"[rank {rank}] rendered {len(times)} of {n} frames, avg time per image: {sum(times) / len(times):.3f} s "
+              f"(GPU time per frame; wall {time.time() - t_start:.1f} s including PNG output)")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     return mine

@@ -6,8 +6,9 @@ per rank per step and one flat RCCL gradient all-reduce.
 Same CLI, YAML schema and checkpoint dictionary as the reference (`iter, model_coarse_state_dict, model_fine_state_dict,
 optimizer_state_dict, loss, psnr, background, latent_codes`; two optimizer param groups).  Differences, all outside the
 hot path: ray selection (importance map, p = 0.9 inside the bbox, TR:230-239) draws on the device (nerf.choose_rays: a HIP
-radix select over exponential keys, torch's generator) instead of np.random.choice on the host; no TensorBoard (the validation
-loss / PSNR of TR:427-505 are printed); rank 0 writes checkpoints; on resume the latent codes and
+radix select over exponential keys, torch's generator) instead of np.random.choice on the host; rank 0 writes checkpoints and
+the reference's TensorBoard scalars / validation images (TR:415-424, 518-541; a JSON-lines file when the `tensorboard` package
+is absent), accumulated on the device and flushed on the iterations that print; on resume the latent codes and
 background are restored *into* the tensors the optimizer already owns (the reference re-wraps them and the optimizer
 keeps stepping the stale ones).
 """
@@ -25,11 +26,17 @@ from .common import D, nerf
 
 
 def importance_maps(bboxs, H, W, p=0.9):
+    """Per-pixel selection weights, indexed by the ROW-MAJOR pixel index row * W + col that nerf.choose_rays / nerf.get_ray_batch use.
+    The reference draws an index k with probability probs.reshape(-1)[k] (TR:230-239: the (H, W) map, p inside the bbox rows
+    b0:b1 x columns b2:b3) and then looks the pixel up in coords = meshgrid_xy(arange(H), arange(W)).reshape(-1, 2) (TR:302-330),
+    whose k-th entry is (row = k % H, col = k // H) -- the map is applied TRANSPOSED.  A drop-in keeps that training
+    distribution: weight(row, col) = probs.reshape(-1)[col * H + row]."""
     maps = []
     for b in bboxs:
         m = np.full((H, W), 1 - p, dtype=np.float64)
         m[int(b[0]):int(b[1]), int(b[2]):int(b[3])] = p
-        maps.append((m / m.sum()).reshape(-1))
+        flat = (m / m.sum()).reshape(-1)                                   # the reference's probs[img_idx]
+        maps.append(np.ascontiguousarray(flat.reshape(W, H).T).reshape(-1))   # [row * W + col] = flat[col * H + row]
     return maps
 
 
@@ -91,6 +98,15 @@ def main(argv=None):
     model_c.train()
     if model_f is not None:
         model_f.train()
+    log = CM.ScalarLog(logdir) if rank == 0 else None
+    if rank == 0:
+        print(f"[LOG] scalars -> {log.kind} ({logdir})")
+    f16 = args.precision == "f16x3"
+    if f16:
+        # split-fp16 range guard, armed for training: the exact-f32 probe of the hidden activations runs on a model's first step
+        # and every print_every-th after it, and the kernels' sticky non-finite flag is polled on the same iterations and at
+        # every checkpoint (the only iterations that synchronise with the host anyway)
+        nerf.ops.set_f16_train_probe_every(cfg.experiment.print_every)
     n_rays = cfg.nerf.train.num_random_rays
     t0 = time.time()
     first_draw = None
@@ -108,11 +124,12 @@ def main(argv=None):
         rgb_c, _, _, rgb_f, _, _, _ = nerf.run_one_iter_of_nerf(
             H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="train", encode_position_fn=enc_xyz,
             encode_direction_fn=enc_dir, expressions=expr, background_prior=bg, latent_code=latent)
-        loss = torch.nn.functional.mse_loss(rgb_c[..., :3], target[..., :3])
-        if rgb_f is not None:
-            loss = loss + torch.nn.functional.mse_loss(rgb_f[..., :3], target[..., :3])
+        coarse_loss = torch.nn.functional.mse_loss(rgb_c[..., :3], target[..., :3])
+        fine_loss = torch.nn.functional.mse_loss(rgb_f[..., :3], target[..., :3]) if rgb_f is not None else None
+        loss = coarse_loss if fine_loss is None else coarse_loss + fine_loss
         mse = loss.detach()                                    # read back (a host sync) only on the iterations that log or save
-        loss = loss + 10 * (torch.norm(latent) * 0.0005)       # TR:375-387
+        code_loss = torch.norm(latent) * 0.0005
+        loss = loss + 10 * code_loss                           # TR:375-387
         loss.backward()
         reducer.reduce()
         optimizer.step()
@@ -120,7 +137,19 @@ def main(argv=None):
         lr_new = cfg.optimizer.lr * (cfg.scheduler.lr_decay_factor ** (i / (cfg.scheduler.lr_decay * 1000)))
         for g in optimizer.param_groups:
             g["lr"] = lr_new
-        if rank == 0 and (i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1):
+        logs_now = i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1
+        saves_now = i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1
+        if f16 and (logs_now or saves_now):
+            nerf.ops.check_f16_range(model_c, model_f)         # every rank: raises if any step since the last poll overflowed fp16
+        if rank == 0:
+            # TR:415-424, device-side: the scalars of every iteration, read back together when the iteration prints
+            log.add_scalar("train/code_loss", code_loss.detach(), i)
+            log.add_scalar("train/coarse_loss", coarse_loss.detach(), i)
+            if fine_loss is not None:
+                log.add_scalar("train/fine_loss", fine_loss.detach(), i)
+            log.add_scalar("train/psnr", -10.0 * torch.log10(mse.clamp_min(1e-20)), i)
+        if rank == 0 and logs_now:
+            log.flush()
             print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {nerf.mse2psnr(mse.item()):.4f} "
                   f"({(time.time() - t0):.1f} s, {world} GPU)")
         if i % cfg.experiment.validate_every == 0:
@@ -133,6 +162,8 @@ def main(argv=None):
                 model_f.eval()
             with torch.no_grad():
                 val_sum = torch.zeros(1, device=dev)
+                val_parts = torch.zeros(2, device=dev)                     # [sum of coarse mse, sum of fine mse] (TR:518-541)
+                val_img = None
                 for j, v_idx in enumerate(i_val[:2]):
                     if j % world != rank:
                         continue
@@ -143,27 +174,52 @@ def main(argv=None):
                         encode_direction_fn=enc_dir, expressions=expr,
                         background_prior=background.view(-1, 3) if background is not None else None,
                         latent_code=torch.zeros(32, device=dev))
-                    v_loss = nerf.img2mse(v_out[0][..., :3], v_img[..., :3])
+                    v_coarse = nerf.img2mse(v_out[0][..., :3], v_img[..., :3])
+                    v_loss = v_coarse
+                    val_parts[0] += v_coarse
                     if v_out[3] is not None:
-                        v_loss = 2.0 * nerf.img2mse(v_out[3][..., :3], v_img[..., :3])
+                        v_fine = nerf.img2mse(v_out[3][..., :3], v_img[..., :3])
+                        v_loss = 2.0 * v_fine
+                        val_parts[1] += v_fine
                     val_sum += v_loss
-                if world > 1:
+                    if rank == 0 and val_img is None:
+                        val_img = (v_out[0], v_out[3], v_img)
+                if torch.distributed.is_initialized() and not D._skip_collectives(world):
                     torch.distributed.all_reduce(val_sum)
+                    torch.distributed.all_reduce(val_parts)
                 val_loss = float(val_sum) / max(len(i_val), 1)
+                if rank == 0:
+                    log.add_scalar("validation/loss", val_loss, i)
+                    log.add_scalar("validation/coarse_loss", val_parts[0] / max(len(i_val), 1), i)
+                    log.add_scalar("validation/psnr", nerf.mse2psnr(val_loss), i)
+                    if model_f is not None:
+                        log.add_scalar("validation/fine_loss", val_parts[1] / max(len(i_val), 1), i)
+                    if val_img is not None:                                # TR:528-541: images of the first validation frame
+                        log.add_image("validation/rgb_coarse", val_img[0][..., :3].permute(2, 0, 1), i)
+                        if val_img[1] is not None:
+                            log.add_image("validation/rgb_fine", val_img[1][..., :3].permute(2, 0, 1), i)
+                        log.add_image("validation/img_target", val_img[2][..., :3].permute(2, 0, 1), i)
+                        if background is not None:
+                            log.add_image("validation/background", background[..., :3].permute(2, 0, 1), i)
+                    log.flush()
             if rank == 0:
                 print(f"[VAL] Iter: {i} Validation loss: {val_loss:.6f} Validation PSNR: {nerf.mse2psnr(val_loss):.4f} "
                       f"({(time.time() - t0):.1f} s)")
             model_c.train()
             if model_f is not None:
                 model_f.train()
-        if rank == 0 and (i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1):
+        if rank == 0 and saves_now:
             psnr = nerf.mse2psnr(mse.item())
             torch.save({"iter": i, "model_coarse_state_dict": model_c.state_dict(),
                         "model_fine_state_dict": None if model_f is None else model_f.state_dict(),
                         "optimizer_state_dict": optimizer.state_dict(), "loss": loss, "psnr": psnr,
                         "background": None if background is None else background.data, "latent_codes": latent_codes.data},
                        os.path.join(logdir, "checkpoint" + str(i).zfill(5) + ".ckpt"))
+    if rank == 0:
+        log.close()
     if torch.distributed.is_initialized():
+        if first_draw is None:                                 # resumed at or past train_iters: the loop never ran
+            first_draw = (-1, torch.full((16,), -1, dtype=torch.int64, device=dev))
         # replica consistency: after identical Adam steps on averaged gradients every rank must hold the same parameters, and
         # the ranks must have drawn different frames / rays (one checksum + the first draw per rank, gathered once at the end)
         import json

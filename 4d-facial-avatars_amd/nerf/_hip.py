@@ -59,6 +59,7 @@ _PROTOTYPES = {
     "nf_paper_grad_floats": (_Z, []),
     "nf_paper_bwd_workspace_floats": (_Z, [_L]),
     "nf_paper_mlp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
+    "nf_paper_mlp_bwd_stage_ms": (C.c_int, [_P, _P, _I, _P, _P, _P, _L, _I, _P, _Z, _P, _P, _P]),
     "nf_lcode_packed_floats": (_Z, []),
     "nf_lcode_cond_floats": (_Z, []),
     "nf_lcode_pack": (C.c_int, [_P, _P, _P]),
@@ -114,6 +115,7 @@ _PROTOTYPES = {
     "nf_resample_merge": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "nf_render_rays_workspace_floats": (_Z, [_L, _I, _I]),
     "nf_render_rays_fwd": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),
+    "nf_render_rays_fwd_f16": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),
     "nf_sort_rows": (C.c_int, [_P, _L, _I, _P, _P]),
 }
 # entry points that later ABI revisions add; absent symbols only fail when called

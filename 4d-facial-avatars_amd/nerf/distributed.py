@@ -11,10 +11,22 @@ is added here is exactly what the path needs:
 """
 from __future__ import annotations
 
+import os
 from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
+
+
+def force_collectives_requested() -> bool:
+    """NERFACE_DIST_FORCE=1: exercise the N > 1 path at world size 1 (see launch.common.init_distributed)."""
+    return os.environ.get("NERFACE_DIST_FORCE", "0") not in ("", "0")
+
+
+def _skip_collectives(world: int) -> bool:
+    """At world size 1 a collective is the identity and is skipped -- unless a process group exists and the run asked for
+    them (then RCCL really runs: a 1-rank all-reduce / broadcast on device memory)."""
+    return world == 1 and not (force_collectives_requested() and dist.is_available() and dist.is_initialized())
 
 
 def world_info():
@@ -98,7 +110,7 @@ class GradientAllReducer:
 
     def reduce(self) -> None:
         _, world = world_info()
-        if world == 1:
+        if _skip_collectives(world):
             return
         device = self.params[0].device
         if self.mask is None:
@@ -127,7 +139,7 @@ def broadcast_parameters(params: Sequence[torch.Tensor], src: int = 0, group=Non
     (data_ptr, version): so the counters are bumped explicitly afterwards (one multi-tensor `x *= 1`), which invalidates
     every cached weight image that was packed before the broadcast."""
     _, world = world_info()
-    if world == 1:
+    if _skip_collectives(world):
         return
     with torch.no_grad():
         for p in params:

@@ -81,7 +81,7 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
             if ph is not None:
                 # range probe (see the inference branch): weights move every step, so probe the first call and every 128th
                 n_calls = self.__dict__["_f16_train_calls"] = self.__dict__.get("_f16_train_calls", 0) + 1
-                if n_calls % 128 == 1:
+                if ops.f16_train_probe_every() == 1 or n_calls % ops.f16_train_probe_every() == 1:
                     amax = ops.f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far)
                     if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
                         raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g}, '
@@ -206,6 +206,13 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             dev = H.require_device(*[p.detach() for p in ps])
             lib = H.lib()
             buf = hit[1] if hit is not None and hit[1].device == dev else torch.empty(getattr(lib, size_fn)(), dtype=dtype, device=dev)
+            if kind == "f16" and hit is not None and hit[1] is buf:
+                # packing clears the stream's range-guard flag: carry it over first (cf. ops.PaperWeights._get)
+                sticky = self.__dict__.get("_f16_sticky")
+                if sticky is None or sticky.device != dev:
+                    sticky = self.__dict__["_f16_sticky"] = torch.zeros((), dtype=torch.int32, device=dev)
+                off = lib.nf_lcode_f16_flag_offset()
+                sticky.bitwise_or_(buf[off:off + 4].view(torch.int32)[0])
             arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
             with torch.cuda.device(dev):
                 H.check(getattr(lib, pack_fn)(arr, H.ptr(buf), H.stream_ptr(dev)), pack_fn)
@@ -235,7 +242,9 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                 if hit is None:
                     return None
                 off = H.lib().nf_lcode_f16_flag_offset()
-                return hit[1][off:off + 4].view(torch.int32)[0]
+                flag = hit[1][off:off + 4].view(torch.int32)[0]
+                sticky = model.__dict__.get("_f16_sticky")
+                return flag if sticky is None else torch.bitwise_or(flag, sticky)
         return _W()
 
     def _f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far, max_rays=256, max_samples=8):
@@ -293,7 +302,7 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             if split == "f16" and not getattr(self, "_in_f16_probe", False):
                 # range probe (weights move every step): the first training call and every 128th
                 n_calls = self.__dict__["_f16_train_calls"] = self.__dict__.get("_f16_train_calls", 0) + 1
-                if n_calls % 128 == 1:
+                if ops.f16_train_probe_every() == 1 or n_calls % ops.f16_train_probe_every() == 1:
                     self._in_f16_probe = True
                     try:
                         amax = self._f16_preflight(ro, rd, z, rd_view, expr, latent, near, far)

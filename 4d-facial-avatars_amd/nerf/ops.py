@@ -204,121 +204,87 @@ def pack_epoch() -> int:
 
 
 class PaperWeights:
-    """Fragment-ordered weight image of one ConditionalBlendshapePaperNeRFModel on one device, re-packed
-    whenever a parameter's version counter moves (i.e. after optimizer.step() / load_state_dict())."""
+    """Kernel-ready images of one ConditionalBlendshapePaperNeRFModel on one device, one per kind, each re-packed whenever a
+    parameter's version counter or the pack epoch moves (i.e. after optimizer.step() / load_state_dict() / a new frame or step):
+      f32 / f32_t      fragment-ordered f32 image for the forward / transposed image for the backward chain
+      bf16 / bf16_t    (hi, lo) bf16 streams of the split-bf16 forward / chain
+      f16 / f16_t      (hi, lo) fp16 streams + per-layer scales of the split-fp16 forward / chain."""
+
+    # kind -> (size function, pack function, element dtype)
+    _KINDS = {
+        "f32": ("nf_paper_packed_floats", "nf_paper_pack", torch.float32),
+        "f32_t": ("nf_paper_packed_bwd_floats", "nf_paper_pack_bwd", torch.float32),
+        "bf16": ("nf_paper_packed_bf16_bytes", "nf_paper_pack_bf16", torch.uint8),
+        "bf16_t": ("nf_paper_packed_bwd_bf16_bytes", "nf_paper_pack_bwd_bf16", torch.uint8),
+        "f16": ("nf_paper_packed_f16_bytes", "nf_paper_pack_f16", torch.uint8),
+        "f16_t": ("nf_paper_packed_bwd_f16_bytes", "nf_paper_pack_bwd_f16", torch.uint8),
+    }
 
     def __init__(self, params: Sequence[torch.Tensor]):
         assert len(params) == H.NF_PAPER_NUM_PARAMS
         self._params = list(params)
-        self._versions = None
-        self._ptrs = None
-        self.packed = None
-        self.packed_t = None            # transposed image for the backward chain (lazily built)
-        self._versions_t = None
-        self.packed_b = None            # (hi, lo) bf16 stream for the split-bf16 forward (lazily built)
-        self._versions_b = None
-        self.packed_bt = None           # transposed (hi, lo) bf16 stream for the split-bf16 backward chain
-        self._versions_bt = None
-        self.packed_h = None            # (hi, lo) fp16 stream + per-layer scales for the split-fp16 forward
-        self._versions_h = None
-        self.packed_ht = None           # transposed (hi, lo) fp16 stream + scales for the split-fp16 backward chain
-        self._versions_ht = None
+        self._cache = {}                # kind -> (signature, buffer)
+        self._f16_sticky = None         # range-guard flag of the split-fp16 forward carried across re-packs (0-d int32 on the device)
 
     def invalidate(self) -> None:
         """Drop every cached image.  The caches follow in-place updates through the parameters' version counters
         (optimizer.step(), load_state_dict(), copy_ under no_grad); writes that bypass the counter -- through `p.data`, or by
         a collective -- are NOT seen: call this (or model.hip_weights().invalidate()) after such a write."""
-        self._versions = self._versions_t = self._versions_b = self._versions_bt = self._versions_h = self._versions_ht = None
-
-    def get_f16_t(self) -> torch.Tensor:
-        sig = self._signature()
-        if self.packed_ht is None or sig != self._versions_ht:
-            dev = H.require_device(*[p.detach() for p in self._params])
-            lib = H.lib()
-            if self.packed_ht is None or self.packed_ht.device != dev:
-                self.packed_ht = torch.empty(lib.nf_paper_packed_bwd_f16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack_bwd_f16(arr, H.ptr(self.packed_ht), H.stream_ptr(dev)), "nf_paper_pack_bwd_f16")
-            self._versions_ht = sig
-        return self.packed_ht
-
-    def get_f16(self) -> torch.Tensor:
-        sig = self._signature()
-        if self.packed_h is None or sig != self._versions_h:
-            dev = H.require_device(*[p.detach() for p in self._params])
-            lib = H.lib()
-            if self.packed_h is None or self.packed_h.device != dev:
-                self.packed_h = torch.empty(lib.nf_paper_packed_f16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack_f16(arr, H.ptr(self.packed_h), H.stream_ptr(dev)), "nf_paper_pack_f16")
-            self._versions_h = sig
-        return self.packed_h
-
-    def f16_range_flag(self) -> Optional[torch.Tensor]:
-        """0-d int32 device tensor: non-zero once the split-fp16 forward produced a non-finite output with the current stream
-        (an activation left fp16's range).  None if the split-fp16 stream was never built."""
-        if self.packed_h is None:
-            return None
-        off = H.lib().nf_paper_f16_flag_offset()
-        return self.packed_h[off:off + 4].view(torch.int32)[0]
-
-    def get_t(self) -> torch.Tensor:
-        """Transposed fragment image for the backward chain (nf_paper_pack_bwd), cached like `packed`."""
-        sig = self._signature()
-        if self.packed_t is None or sig != self._versions_t:
-            dev = H.require_device(*[p.detach() for p in self._params])
-            lib = H.lib()
-            if self.packed_t is None or self.packed_t.device != dev:
-                self.packed_t = torch.empty(lib.nf_paper_packed_bwd_floats(), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack_bwd(arr, H.ptr(self.packed_t), H.stream_ptr(dev)), "nf_paper_pack_bwd")
-            self._versions_t = sig
-        return self.packed_t
-
-    def get_bf16_t(self) -> torch.Tensor:
-        sig = self._signature()
-        if self.packed_bt is None or sig != self._versions_bt:
-            dev = H.require_device(*[p.detach() for p in self._params])
-            lib = H.lib()
-            if self.packed_bt is None or self.packed_bt.device != dev:
-                self.packed_bt = torch.empty(lib.nf_paper_packed_bwd_bf16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack_bwd_bf16(arr, H.ptr(self.packed_bt), H.stream_ptr(dev)), "nf_paper_pack_bwd_bf16")
-            self._versions_bt = sig
-        return self.packed_bt
-
-    def get_bf16(self) -> torch.Tensor:
-        sig = self._signature()
-        if self.packed_b is None or sig != self._versions_b:
-            dev = H.require_device(*[p.detach() for p in self._params])
-            lib = H.lib()
-            if self.packed_b is None or self.packed_b.device != dev:
-                self.packed_b = torch.empty(lib.nf_paper_packed_bf16_bytes(), dtype=torch.uint8, device=dev)
-            arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack_bf16(arr, H.ptr(self.packed_b), H.stream_ptr(dev)), "nf_paper_pack_bf16")
-            self._versions_b = sig
-        return self.packed_b
+        for kind, (_, buf) in list(self._cache.items()):
+            self._cache[kind] = (None, buf)
 
     def _signature(self):
         return (_PACK_EPOCH[0],) + tuple((int(p.data_ptr()), int(p._version)) for p in self._params)
 
-    def get(self) -> torch.Tensor:
+    def _get(self, kind: str) -> torch.Tensor:
         sig = self._signature()
-        if self.packed is None or sig != self._versions:
+        hit = self._cache.get(kind)
+        if hit is None or hit[0] != sig:
+            size_fn, pack_fn, dtype = self._KINDS[kind]
             dev = H.require_device(*[p.detach() for p in self._params])
             lib = H.lib()
-            if self.packed is None or self.packed.device != dev:
-                self.packed = torch.empty(lib.nf_paper_packed_floats(), dtype=torch.float32, device=dev)
+            buf = hit[1] if hit is not None and hit[1].device == dev else torch.empty(getattr(lib, size_fn)(), dtype=dtype, device=dev)
+            if kind == "f16" and hit is not None and hit[1] is buf:
+                # packing clears the stream's range-guard flag: carry it over first (one tiny device op, no host sync), so that a
+                # training run polled every print_every iterations still sees an overflow of any iteration in between
+                if self._f16_sticky is None or self._f16_sticky.device != dev:
+                    self._f16_sticky = torch.zeros((), dtype=torch.int32, device=dev)
+                off = lib.nf_paper_f16_flag_offset()
+                self._f16_sticky.bitwise_or_(buf[off:off + 4].view(torch.int32)[0])
             arr = (C.c_void_p * H.NF_PAPER_NUM_PARAMS)(*[int(p.data_ptr()) for p in self._params])
             with torch.cuda.device(dev):
-                H.check(lib.nf_paper_pack(arr, H.ptr(self.packed), H.stream_ptr(dev)), "nf_paper_pack")
-            self._versions = sig
-        return self.packed
+                H.check(getattr(lib, pack_fn)(arr, H.ptr(buf), H.stream_ptr(dev)), pack_fn)
+            self._cache[kind] = (sig, buf)
+        return self._cache[kind][1]
+
+    def get(self) -> torch.Tensor:
+        return self._get("f32")
+
+    def get_t(self) -> torch.Tensor:
+        return self._get("f32_t")
+
+    def get_bf16(self) -> torch.Tensor:
+        return self._get("bf16")
+
+    def get_bf16_t(self) -> torch.Tensor:
+        return self._get("bf16_t")
+
+    def get_f16(self) -> torch.Tensor:
+        return self._get("f16")
+
+    def get_f16_t(self) -> torch.Tensor:
+        return self._get("f16_t")
+
+    def f16_range_flag(self) -> Optional[torch.Tensor]:
+        """0-d int32 device tensor: non-zero once a split-fp16 forward of this model produced a non-finite output (an activation
+        left fp16's range) -- with the current stream or, carried over the re-packs of a training run, with any earlier one.
+        None if the split-fp16 stream was never built."""
+        hit = self._cache.get("f16")
+        if hit is None:
+            return None
+        off = H.lib().nf_paper_f16_flag_offset()
+        flag = hit[1][off:off + 4].view(torch.int32)[0]
+        return flag if self._f16_sticky is None else torch.bitwise_or(flag, self._f16_sticky)
 
 
 def paper_condition(packed: torch.Tensor, expr: torch.Tensor, latent: torch.Tensor, near: float, far: float) -> torch.Tensor:
@@ -364,6 +330,18 @@ def paper_mlp_fwd_f16(packed_h, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
         H.check(H.lib().nf_paper_mlp_fwd_f16(H.ptr(packed_h), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
                                              n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd_f16")
     return raw
+
+
+_f16_train_probe_every = [128]           # training: the f32 range probe runs on a model's first forward and every n-th after it
+
+
+def set_f16_train_probe_every(n: int) -> None:
+    """Cadence of the split-fp16 range probe in training (calls per model; the launcher sets it to its print_every)."""
+    _f16_train_probe_every[0] = max(1, int(n))
+
+
+def f16_train_probe_every() -> int:
+    return _f16_train_probe_every[0]
 
 
 F16_ACT_LIMIT = 65504.0 / 16.0          # largest |activation| the split-fp16 kernel represents (fp16 max / its 2^4 pre-scale)

@@ -20,9 +20,12 @@ On the same JSON line (every BASELINE config that fits this box is timed by this
                   rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE: separate passes) run by this command on the same kernel.
   split_bf16   -- the same K frames with nerf.set_mlp_precision("bf16x3") (three bf16 MFMAs per product, f32 accumulate):
                   value, ms, its kernel's roofline against the dense bf16 peak, and its parity on the CPU sample.
-  train        -- configs[2]: 2048-ray training iterations (64+64, fwd + bwd + Adam) in both arithmetics, ms/iter, rays/s
-                  and the HBM roofline of the training MLP kernels (N>1: configs[4], data parallel with the flat all-reduce).
+  train        -- configs[2]: 2048-ray training iterations (64+64, fwd + bwd + Adam) in the three arithmetics, ms/iter, rays/s and
+                  a per-kernel roofline (forward with saves, dX chain, weight-gradient GEMMs: exact f32 against the fp32-MFMA
+                  peak, the split arithmetics against HBM; PMC traffic per launch) (N>1: configs[4], data parallel, flat all-reduce).
   tiny         -- configs[0]: tiny_nerf 64x64x32 forward on the device next to the CPU oracle of the same image.
+  eager_rocm   -- the reference algorithm as stock PyTorch-ROCm eager fp32 ops on the same GPU (bounded ray sample): the same-box
+                  denominator BASELINE.md names next to the CPU one.
   cpu_baseline -- the CPU oracle (port of the reference algorithm, oracle/nerface_oracle.py) timed on this box's host
                   cores on a bounded sample of the same workload (rank 0, N=1 only); `reference_ratio` ties the port to the
                   unmodified reference (both timed in the build container, profiles/r02_port_vs_reference_cpu.json).
@@ -54,6 +57,9 @@ H = W = 512
 N_COARSE, N_FINE = 64, 128
 CHUNK = 65536
 FLOP_PER_POINT = 1_100_032            # algorithmic forward FLOPs of the paper MLP per point
+EXEC_FLOP_PER_POINT_F32 = 999_936     # FLOPs the exact-f32 kernel issues per point: the folded constant columns never enter the GEMMs
+CHAIN_FLOP_PER_POINT = 918_784        # dX chain: 2 x (3*128 + 2*128*128 + 128*256 + 256 + 6*256*256)
+DW_FLOP_PER_POINT = 1_100_032         # weight gradients: one outer product per weight = the forward's products
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3 TB/s is achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
@@ -164,61 +170,130 @@ def cpu_baseline(n_rays=12288):
             ratio = json.load(open(rpath))
         except Exception:
             ratio = None
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "kind": "port",
+    if isinstance(ratio, dict):
+        ratio = {"replayed": True, "measured_in": "the build container (the unmodified reference cannot travel to the GPU box), once, round 2",
+                 "file": "profiles/r02_port_vs_reference_cpu.json", **ratio}
+    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "kind": "port",
+            "cores_note": "`cores` = torch CPU threads the calibration below picked for the timed sample; `host_cores` = os.cpu_count() of this box",
             "reference_ratio": ratio,
             "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s",
             "parity_on_sample": parity}
 
 
-# algorithmic HBM bytes per MLP point of the three training kernels (csrc/nf_mlp_layout.h, nf_mlp_lcode_layout.h): the forward
-# writes the saved activations (+ ReLU bit masks in split-bf16), the chain reads its ReLU gates (+ d_raw) and writes dZ, the
-# weight-gradient GEMMs read every saved activation, every dZ and d_raw once
-TRAIN_BYTES_PER_POINT = {
-    ("paper", "bf16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
-    ("paper", "f32"): 4 * 2256 + (4 * (6 * 256 + 3 * 128) + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
-    ("paper", "f16x3"): 4 * 2328 + (72 + 16) + 4 * 2176 + 4 * (2256 + 2176 + 4),
-    ("lcode", "f32"): 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
-    ("lcode", "bf16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
-    ("lcode", "f16x3"): 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+# algorithmic HBM bytes per MLP point of the three training kernels of the PAPER model (csrc/nf_mlp_layout.h): the forward writes the
+# saved activations + ReLU bit masks (and reads z), the chain reads its ReLU masks + d_raw and writes dZ, the weight-gradient
+# GEMMs read every saved activation, every dZ and d_raw once
+TRAIN_KERNELS = {
+    "f32": (("k_paper_mlp_fwd_save", "forward with saves"), ("k_paper_mlp_bwd_chain_masks", "dX chain"), ("k_dw_gemm_lds", "weight-gradient GEMMs")),
+    "bf16x3": (("k_paper_mlp_fwd_bf16_train", "forward with saves"), ("k_paper_mlp_bwd_chain_bf16", "dX chain"), ("k_paper_dw_gemm_bf16", "weight-gradient GEMMs")),
+    "f16x3": (("k_paper_mlp_fwd_f16_train", "forward with saves"), ("k_paper_mlp_bwd_chain_f16", "dX chain"), ("k_paper_dw_gemm_f16", "weight-gradient GEMMs")),
 }
+TRAIN_BYTES_PER_POINT = (4 * (2256 + 72) + 4 + 16, 4 * 72 + 16 + 4 * 2176, 4 * (2256 + 2176 + 4))
+TRAIN_FLOP_PER_POINT = (FLOP_PER_POINT, CHAIN_FLOP_PER_POINT, DW_FLOP_PER_POINT)
+# (lcode family, --mode train --family lcode: whole-iteration bytes only)
+LCODE_BYTES_PER_POINT = {"f32": 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+                         "bf16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
+                         "f16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4)}
 
 
 def train_roofline(args, model, dev, n_rays):
-    """HBM roofline of the training MLP kernels, measured live with events on the stream they are launched on (torch's current
-    stream): training forward + backward (chain, dW GEMMs, reduction) of one model at the two launch sizes of an iteration
-    (n_rays x 64 coarse, n_rays x 128 fine), algorithmic bytes / time against the 8 TB/s HBM peak."""
+    """Per-kernel roofline of the training MLP kernels of ONE model, measured live with HIP events on the stream they are launched
+    on: the training forward (its own C call) and the three stages of the backward call (nf_paper_mlp_bwd_stage_ms records events
+    between the dX chain, the weight-gradient GEMMs and the slab reduction), at the two launch sizes of an iteration
+    (n_rays x 64 coarse, n_rays x 128 fine).  Each kernel is priced against the bound that binds it: exact f32 -> the dense
+    fp32-MFMA peak (it issues one MFMA FLOP per algorithmic FLOP and moves 9-18 KB per point in the same time: MFMA-bound);
+    split arithmetics (3 x 16-bit MFMAs per product, 16x the rate) -> HBM."""
+    import ctypes as C
+    from nerf import _hip as HH
+    from nerf import ops
+    prec = args.precision
+    lib = HH.lib()
     g = torch.Generator(device="cpu").manual_seed(5)
     ro = torch.zeros(n_rays, 3).to(dev)
     rd = (torch.randn(n_rays, 3, generator=g) * 0.3).to(dev)
     expr, lat = (torch.randn(76, generator=g) * 0.5).to(dev), (torch.randn(32, generator=g) * 0.1).to(dev)
-    total_ms, total_pts = 0.0, 0
-    for s in (64, 128):
-        z = torch.sort(torch.rand(n_rays, s, generator=g) * 0.6 + 0.2, dim=-1)[0].to(dev)
-        d_raw = (torch.randn(n_rays, s, 4, generator=g) / (3 * n_rays)).to(dev)
-        def once():
-            raw, state = model.hip_forward(ro, rd, z, rd, expr, lat, NEAR, FAR, True)
-            model.hip_backward(state, z, d_raw)
-        for _ in range(3):
-            once()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        reps = 10
-        e0.record()
-        for _ in range(reps):
-            once()
-        e1.record()
-        torch.cuda.synchronize()
-        total_ms += e0.elapsed_time(e1) / reps
-        total_pts += n_rays * s
-    prec = args.precision
-    bpp = TRAIN_BYTES_PER_POINT[(args.family, prec)]
-    achieved = bpp * total_pts / (total_ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": f"{args.family} MLP training kernels of ONE model per iteration (training forward + dX chain + dW GEMMs "
-                                      f"+ reduction; {n_rays} x 64 and {n_rays} x 128 points)",
-            "achieved": achieved, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": achieved / PEAK_HBM_GBS, "traffic": None,
-            "algorithmic_bytes_per_point": bpp, "ms_both_launches": total_ms,
-            "note": "per iteration the coarse model runs the 64-sample launch and the fine model the 128-sample launch, so "
-                    "ms_both_launches is the MLP-kernel time of one iteration; a dedicated rocprofv3 pass (profiles/) gives the "
-                    "per-kernel split and the PMC HBM bytes"}
+    if args.family != "paper":                                             # second family: the whole-iteration figure only
+        total_ms, total_pts = 0.0, 0
+        for s_ in (64, 128):
+            z = torch.sort(torch.rand(n_rays, s_, generator=g) * 0.6 + 0.2, dim=-1)[0].to(dev)
+            d_raw = (torch.randn(n_rays, s_, 4, generator=g) / (3 * n_rays)).to(dev)
+
+            def once():
+                raw, state = model.hip_forward(ro, rd, z, rd, expr, lat, NEAR, FAR, True)
+                model.hip_backward(state, z, d_raw)
+            for _ in range(3):
+                once()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(10):
+                once()
+            e1.record()
+            torch.cuda.synchronize()
+            total_ms += e0.elapsed_time(e1) / 10
+            total_pts += n_rays * s_
+        bpp = LCODE_BYTES_PER_POINT[prec]
+        ach = bpp * total_pts / (total_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "lcode MLP training kernels of ONE model per iteration", "achieved": ach, "peak": PEAK_HBM_GBS,
+                "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None, "algorithmic_bytes_per_point": bpp, "ms_both_launches": total_ms}
+    hw = model.hip_weights()
+    packed = hw.get()
+    cond = ops.paper_condition(packed, expr, lat, NEAR, FAR)
+    pk_fwd = {"f32": None, "bf16x3": hw.get_bf16(), "f16x3": hw.get_f16()}[prec]
+    pk_bwd = {"f32": hw.get_t, "bf16x3": hw.get_bf16_t, "f16x3": hw.get_f16_t}[prec]()
+    code = {"f32": 0, "bf16x3": 1, "f16x3": 2}[prec]
+    flat = torch.empty(lib.nf_paper_grad_floats(), device=dev)
+    per_size = {}
+    reps = 8
+    for s_ in (64, 128):
+        n = n_rays * s_
+        z = torch.sort(torch.rand(n_rays, s_, generator=g) * 0.6 + 0.2, dim=-1)[0].to(dev)
+        d_raw = (torch.randn(n_rays, s_, 4, generator=g) / (3 * n_rays)).to(dev)
+        ws_floats = lib.nf_paper_bwd_workspace_floats(n)
+        ws = torch.empty(ws_floats, device=dev)
+        ms = [0.0, 0.0, 0.0, 0.0]
+        for it in range(reps + 2):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw, (saved,) = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd, packed_b=pk_fwd if prec == "bf16x3" else None,
+                                                    packed_h=pk_fwd if prec == "f16x3" else None)
+            e1.record()
+            st = (C.c_float * 3)()
+            HH.check(lib.nf_paper_mlp_bwd_stage_ms(HH.ptr(packed), HH.ptr(pk_bwd), code, HH.ptr(cond), HH.ptr(saved), HH.ptr(d_raw), n_rays, s_,
+                                                   HH.ptr(ws), ws_floats, HH.ptr(flat), st, HH.stream_ptr(dev)), "nf_paper_mlp_bwd_stage_ms")
+            if it >= 2:                                                    # (the call above synchronised the stream)
+                ms[0] += e0.elapsed_time(e1) / reps
+                for k in range(3):
+                    ms[k + 1] += st[k] / reps
+            del saved
+        per_size[s_] = ms
+        del ws
+    n_big = n_rays * 128
+    kernels = []
+    for k, (kname, what) in enumerate(TRAIN_KERNELS[prec]):
+        t = per_size[128][k] * 1e-3
+        if prec == "f32":
+            ach = TRAIN_FLOP_PER_POINT[k] * n_big / t / 1e12
+            obj = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
+                   "algorithmic_flops_per_point": TRAIN_FLOP_PER_POINT[k]}
+            if k == 0:
+                obj["executed_tflops"] = EXEC_FLOP_PER_POINT_F32 * n_big / t / 1e12
+                obj["frac_executed"] = obj["executed_tflops"] / PEAK_F32_MFMA_TFLOPS
+        else:
+            ach = TRAIN_BYTES_PER_POINT[k] * n_big / t / 1e9
+            obj = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
+        obj.update({"kernel": f"{kname} ({what}; {n_rays} rays x 128 samples per launch)", "avg_launch_ms": per_size[128][k],
+                    "avg_launch_ms_64_samples": per_size[64][k], "algorithmic_hbm_bytes_per_point": TRAIN_BYTES_PER_POINT[k], "traffic": None})
+        kernels.append(obj)
+    total = sum(per_size[64]) + sum(per_size[128])
+    top = max(kernels, key=lambda o: o["avg_launch_ms"])
+    return {**{k: top[k] for k in ("bound", "achieved", "peak", "unit", "frac", "kernel", "avg_launch_ms", "traffic")},   # the dominant kernel
+            "kernels": kernels, "reduce_unpack_ms": {"64_samples": per_size[64][3], "128_samples": per_size[128][3]},
+            "ms_both_launches": total,
+            "note": "per iteration the coarse model runs the 64-sample launch and the fine model the 128-sample launch, so ms_both_launches "
+                    "is the MLP-kernel time of one training iteration; forward timed around its own call, backward stages by HIP events "
+                    "recorded inside nf_paper_mlp_bwd_stage_ms on the launch stream; `traffic` = PMC HBM bytes per launch (filled by the "
+                    "eval line's PMC passes, tools/pmc_train_launch.py)"}
 
 
 def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True):
@@ -248,6 +323,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     importance = torch.full((H, W), 0.1, device=dev)                   # the trainer's importance map (TR:230-239) for a centred face box
     importance[H // 5: 4 * H // 5, W // 4: 3 * W // 4] = 0.9
     importance = (importance / importance.sum()).reshape(-1)
+    importance = importance.reshape(W, H).T.contiguous().reshape(-1)   # the reference applies the map transposed (launch.train_sharded.importance_maps)
     n_it = args.steps + args.warmup
     frame_ids = torch.randint(0, n_train, (n_it,)).tolist()
     poses = [frame_pose(f).to(dev) for f in frame_ids]
@@ -397,6 +473,49 @@ def cpu_baseline_tiny(params, pose, focal, reps=3):
             "sample": f"{reps} whole 64x64x32 images"}
 
 
+def eager_rocm_baseline(dev, n_rays=32768, chunk=8192):
+    """The same-GPU stock-PyTorch denominator (BASELINE.md sections 1, 3): the reference ALGORITHM as PyTorch-ROCm eager fp32 ops on this
+    device -- the oracle's torch restatement with its tensors moved to the GPU, rays fed `chunk` at a time (the reference's 65536-ray
+    chunks would need > 4 GB per concatenated MLP input) -- on a bounded sample of the headline workload (n_rays rays of one 512x512
+    frame, 64+128 samples, deterministic sampling).  A baseline leg like cpu_baseline: the oracle is the thing timed, never the product."""
+    from oracle import cases as C
+    from oracle import nerface_oracle as O
+    c = C.build_case("eval_det_64_128")
+    ro, rd, bg, _, _ = C.ray_subset(H, W, 3, n_rays, seed=5)
+    pc = {k: v.to(dev) for k, v in c["p_coarse"].items()}
+    pf = {k: v.to(dev) for k, v in c["p_fine"].items()}
+    ro, rd, bg = ro.to(dev), rd.to(dev), bg.to(dev)
+    expr, lat = c["expr"].to(dev), c["latent"].to(dev)
+
+    def run():
+        outs = []
+        with torch.no_grad():
+            for i in range(0, n_rays, chunk):
+                r = min(chunk, n_rays - i)
+                z = O.coarse_z(r, O.NEAR, O.FAR, 64, None).to(dev)
+                raw = O.paper_mlp(pc, O.encode_points(ro[i:i + r], rd[i:i + r], z, O.NEAR, O.FAR), expr, lat).reshape(r, 64, 4).clone()
+                raw[:, -1, :3] = bg[i:i + r]
+                _, _, _, w = O.volume_render(raw, z, rd[i:i + r], None, True)
+                zm = 0.5 * (z[:, 1:] + z[:, :-1])
+                u = torch.linspace(0, 1, 128, device=dev).expand(r, 128)
+                zs = O.sample_pdf(zm, w[:, 1:-1], 128, u)
+                zf, _ = torch.sort(torch.cat((z, zs), -1), -1)
+                raw = O.paper_mlp(pf, O.encode_points(ro[i:i + r], rd[i:i + r], zf, O.NEAR, O.FAR), expr, lat).reshape(r, 192, 4).clone()
+                raw[:, -1, :3] = bg[i:i + r]
+                outs.append(O.volume_render(raw, zf, rd[i:i + r], None, True)[0])
+        return torch.cat(outs)
+    run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert bool(torch.isfinite(out).all())
+    return {"value": n_rays / dt, "unit": "rays/s", "kind": "port", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
+            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, ray chunk {chunk}, oracle ops on {torch.cuda.get_device_name(dev)}, {dt * 1e3:.0f} ms",
+            "note": "stock PyTorch-ROCm eager execution of the reference algorithm on the same GPU; the reference's own scripts cannot run on this box"}
+
+
 def device_info(dev):
     """What the box reports (re-derive the peaks from the clocks of the GPU box): CUs x 256 fp32-MFMA FLOP per clock x
     the engine clock, beside the vendor figure the roofline is priced against."""
@@ -416,14 +535,12 @@ def device_info(dev):
             "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
 
 
-def pmc_traffic(precision, timeout=240):
-    """HBM bytes per fine-pass MLP launch, measured by THIS command: rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot
-    share a pass on gfx950, MI355X_MICROARCH.md) over tools/pmc_one_launch.py, which launches exactly the kernel the roofline
-    object times.  FETCH_SIZE / WRITE_SIZE are KiB; raw counters, no 2x correction (the dominant reads are 4-byte z loads,
-    not the 16 B/lane stream the guide's correction is calibrated on).  Returns (bytes or None, detail dict)."""
+def pmc_kernel_bytes(script, argv, kernels, timeout=240):
+    """HBM bytes per launch of the named kernels, measured by THIS command: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
+    cannot share a pass on gfx950, MI355X_MICROARCH.md) over tools/<script> <argv>.  Per kernel (substring match, its largest grid):
+    {"fetch_bytes", "write_bytes"}, the counters' KiB x 1024, raw.  Returns (dict or None, detail)."""
     import shutil
     import sqlite3
-    import subprocess
     import tempfile
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
@@ -433,8 +550,7 @@ def pmc_traffic(precision, timeout=240):
     under = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER"))]
     if under or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
         return None, {"skipped": "bench.py is running under a profiler (" + ", ".join(sorted(under)[:4]) + "); PMC passes not nested"}
-    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
-    got = {}
+    got = {k: {} for k in kernels}
     tmp = tempfile.mkdtemp(prefix="nf_pmc_")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -442,27 +558,58 @@ def pmc_traffic(precision, timeout=240):
             env = dict(os.environ, TMPDIR=tmp)
             env.pop("RANK", None)
             env.pop("WORLD_SIZE", None)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable,
-                   os.path.join(ROOT, "tools", "pmc_one_launch.py"), precision]
+            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script), *argv]
             r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
             dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if r.returncode != 0 or not dbs:
                 return None, {"error": f"rocprofv3 pass {counter} failed (rc {r.returncode})", "tail": r.stdout.decode()[-400:]}
             rows = sqlite3.connect(dbs[0]).execute(
                 "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()
-            hits = [(gx, v) for n, gx, v in rows if kernel in n]
-            big = max((gx for gx, _ in hits), default=None)               # the fine-pass launch is the kernel's largest grid
-            vals = [v for gx, v in hits if gx == big]
-            if not vals:
-                return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _ in rows})[:8]}
-            got[counter] = sum(vals) / len(vals) * 1024.0
-        return got["FETCH_SIZE"] + got["WRITE_SIZE"], {"fetch_bytes": got["FETCH_SIZE"], "write_bytes": got["WRITE_SIZE"],
-                                                       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) "
-                                                                 "run by bench.py on tools/pmc_one_launch.py in this run"}
+            for kernel in kernels:
+                hits = [(gx, v) for n, gx, v in rows if kernel in n]
+                big = max((gx for gx, _ in hits), default=None)           # the launch of interest is the kernel's largest grid
+                vals = [v for gx, v in hits if gx == big]
+                if not vals:
+                    return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _ in rows})[:8]}
+                got[kernel]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = sum(vals) / len(vals) * 1024.0
+        return got, {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) run by bench.py on tools/{script} "
+                               + " ".join(argv) + " in this run"}
     except Exception as e:
         return None, {"error": repr(e)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_traffic(precision, timeout=240):
+    """HBM bytes per fine-pass MLP launch of the eval kernel of `precision` (tools/pmc_one_launch.py launches exactly the kernel
+    the roofline object times).  Raw counters, no 2x correction (the dominant reads are 4-byte z loads, not the 16 B/lane stream
+    the guide's correction is calibrated on).  Returns (bytes or None, detail dict)."""
+    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
+    got, detail = pmc_kernel_bytes("pmc_one_launch.py", [precision], [kernel], timeout)
+    if got is None:
+        return None, detail
+    detail.update(got[kernel])
+    return got[kernel]["fetch_bytes"] + got[kernel]["write_bytes"], detail
+
+
+def pmc_train_traffic(train, timeout=300):
+    """Fill `traffic` of every training kernel of the `train` object (all arithmetics in one pair of PMC passes).  The training
+    kernels read with 16-byte lanes (dwordx4 / LDS-DMA), the access width for which MI355X_MICROARCH.md calibrates FETCH_SIZE at
+    half the bytes: `traffic` = 2 x fetch + write, the raw counters are kept beside it.  (The split weight-gradient kernels read
+    4 bytes per lane: raw.)"""
+    precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
+    names = [k for p in precs for k, _ in TRAIN_KERNELS[p]]
+    got, detail = pmc_kernel_bytes("pmc_train_launch.py", precs, names, timeout)
+    for p in precs:
+        for (kname, _), obj in zip(TRAIN_KERNELS[p], train[p]["roofline"]["kernels"]):
+            if got is None:
+                obj["traffic_detail"] = detail
+                continue
+            f, w = got[kname]["fetch_bytes"], got[kname]["write_bytes"]
+            wide = not kname.startswith("k_paper_dw_gemm_")
+            obj["traffic"] = (2 * f if wide else f) + w
+            obj["traffic_detail"] = {"fetch_bytes_raw": f, "write_bytes": w, "fetch_correction": "x2 (16 B/lane reads)" if wide else "none (4 B/lane reads)",
+                                     "algorithmic_bytes_per_launch": obj["algorithmic_hbm_bytes_per_point"] * 2048 * 128, **detail}
 
 
 def main():
@@ -497,7 +644,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    force_pg = os.environ.get("NERFACE_DIST_FORCE", "0") not in ("", "0")   # world 1 under torch.distributed.run: run the collectives anyway (RCCL smoke)
+    if world > 1 or force_pg:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -610,6 +758,8 @@ def main():
                                  "latent table 1000x32, fwd + bwd + fused Adam" + ("" if world == 1 else
                                  f"; configs[4]: data parallel over {world} GPUs, one frame per rank, flat gradient all-reduce (RCCL)"))
             line["train"] = train
+            if world == 1:
+                pmc_train_traffic(train)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: fused MLP forward, fine pass of one ray chunk ----------------
@@ -641,7 +791,12 @@ def main():
         objs = {"f32": {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2,false> (65536 rays x 192 samples per launch)",
                         "achieved": flops / (ms["f32"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms["f32"],
-                        "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes, "traffic": None}}
+                        "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes, "traffic": None,
+                        "executed_tflops": float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12,
+                        "frac_executed": float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "note": "achieved counts the ALGORITHMIC FLOPs of the reference MLP (1,100,032 per point); the kernel folds the per-frame "
+                                "constant input columns (expression, latent code, PE(near), PE(far)) into bias vectors and issues 999,936 "
+                                "MFMA FLOPs per point: executed_tflops / frac_executed (= the matrix pipe's busy fraction, PMC: profiles/r03_mlp_f32_pmc.md)"}}
         for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
             exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms[prec] * 1e-3) / 1e12
@@ -668,6 +823,13 @@ def main():
             except Exception as e:                                # an extra must never cost the headline
                 line["tiny"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
+            try:
+                torch.cuda.empty_cache()
+                line["eager_rocm"] = eager_rocm_baseline(dev)
+                line["eager_rocm"]["product_over_eager"] = line["value"] / line["eager_rocm"]["value"]
+            except Exception as e:                                # an extra must never cost the headline
+                line["eager_rocm"] = {"error": repr(e)}
+            torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
             par = line["cpu_baseline"].get("parity_on_sample", {})
             for other in others:

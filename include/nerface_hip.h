@@ -154,6 +154,14 @@ int nf_paper_mlp_bwd(const float* packed, const float* packed_t, const float* co
                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
                      size_t workspace_floats, float* grads, nf_stream_t stream);
 
+/* Measurement hook (bench.py's per-kernel training roofline; the reference has no counterpart): one backward in arithmetic
+ * `precision` (0 exact f32, 1 split-bf16, 2 split-fp16; packed_t_any = the matching transposed image / stream) with HIP
+ * events recorded on `stream` between its stages.  Synchronises the stream; stage_ms[3] (host) = {dX chain,
+ * weight-gradient GEMMs, slab reduction + unpack} in milliseconds.                                                  */
+int nf_paper_mlp_bwd_stage_ms(const float* packed, const void* packed_t_any, int precision, const float* cond,
+                              const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
+                              size_t workspace_floats, float* grads, float* stage_ms, nf_stream_t stream);
+
 /* Backward on the split-bf16 kernels: the dX chain and (unless exact_dw != 0) the weight-gradient GEMMs; bias/latent
  * reductions stay f32.  `saved` must have been written by nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks
  * the chain reads).                                                                                                  */
@@ -298,6 +306,15 @@ int nf_render_rays_fwd(const float* packed_coarse, const void* packed_bf16_coars
                        int64_t n_rays, int n_coarse, int n_fine, float near_z, float far_z, int white_background,
                        float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
                        float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
+
+/* The same pipeline with the split-fp16 MLP kernels: packed_f16_* = streams of nf_paper_pack_f16 (NULL: that network runs exact f32). */
+int nf_render_rays_fwd_f16(const float* packed_coarse, const void* packed_f16_coarse, const float* packed_fine,
+                           const void* packed_f16_fine, const float* expr76, const float* latent32, const float* ro,
+                           const float* rd, const float* rd_view, const float* bg, const float* t_vals, const float* t_rand,
+                           const float* u, int64_t u_row_stride, const float* noise_coarse, const float* noise_fine,
+                           int64_t n_rays, int n_coarse, int n_fine, float near_z, float far_z, int white_background,
+                           float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
+                           float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
 
 /* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
 int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);

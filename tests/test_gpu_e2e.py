@@ -197,14 +197,15 @@ def test_white_background(hip_lib, gpu):
     assert float((d_raw.cpu().double() - raw_l.grad).norm() / raw_l.grad.norm()) < 2e-5
 
 
-@pytest.mark.parametrize("split", [False, True])
+@pytest.mark.parametrize("split", [False, True, "f16"])
 def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
-    """nf_render_rays_fwd (one C call per ray chunk) must reproduce the Python-sequenced kernels bit for bit."""
+    """nf_render_rays_fwd / nf_render_rays_fwd_f16 (one C call per ray chunk) must reproduce the Python-sequenced kernels bit for bit,
+    in the three arithmetics."""
     import nerf
     from nerf import _hip as H
     from nerf import ops
     c = C.build_case("train_rand_64_64")
-    nerf.set_mlp_precision("bf16x3" if split else "f32")
+    nerf.set_mlp_precision({False: "f32", True: "bf16x3", "f16": "f16x3"}[split])
     try:
         out_py, mc, mf, _ = U.run_product(nerf, c, gpu)
     finally:
@@ -218,10 +219,12 @@ def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
             torch.empty(n, device=gpu), torch.empty(n, device=gpu), torch.empty(n, device=gpu)]
     hc, hf = mc.hip_weights(), mf.hip_weights()
     t_vals = ops.linspace01(nc, gpu)
-    args = [hc.get(), hc.get_bf16() if split else None, hf.get(), hf.get_bf16() if split else None, dv(c["expr"]), dv(c["latent"]),
+    stream_of = (lambda h: h.get_f16()) if split == "f16" else ((lambda h: h.get_bf16()) if split else (lambda h: None))
+    args = [hc.get(), stream_of(hc), hf.get(), stream_of(hf), dv(c["expr"]), dv(c["latent"]),
             dv(c["ro"]), dv(c["rd"]), None, dv(c["bg"]), t_vals, dv(c["t_rand"])]
     u, noise_c, noise_f = dv(c["u"]), dv(c["noise_c"]), dv(c["noise_f"])      # keep references: raw pointers do not own memory
-    rc = lib.nf_render_rays_fwd(*[H.ptr(a) for a in args], H.ptr(u), nf, H.ptr(noise_c), H.ptr(noise_f), n, nc, nf,
+    entry = lib.nf_render_rays_fwd_f16 if split == "f16" else lib.nf_render_rays_fwd
+    rc = entry(*[H.ptr(a) for a in args], H.ptr(u), nf, H.ptr(noise_c), H.ptr(noise_f), n, nc, nf,
                                 float(np.float32(O.NEAR)), float(np.float32(O.FAR)), 0, H.ptr(ws), ws_n, *[H.ptr(o) for o in outs],
                                 H.stream_ptr(gpu))
     assert rc == 0
@@ -329,3 +332,42 @@ def test_full_frame_512_vs_fp64_oracle(hip_lib, gpu, family):
                   f"{psnr(ours, ref[k]):.1f} dB, max|d rgb| = {float((ours.double() - ref[k]).abs().max()):.2e}")
             assert dp <= 1e-4, (family, precision, NAMES7[k], dp)
         assert float((out[5].reshape(-1).double() - ref[5]).abs().max()) < 1e-5
+
+
+@pytest.mark.parametrize("family", ["hard", "soft"])
+def test_full_frame_512_stochastic_vs_fp64_oracle(hip_lib, gpu, family):
+    """The same whole-frame gate with the SHIPPED validation setting (perturb: True, CFG:149-167 -- also what bench.py's timed region
+    runs): the stratified jitter t_rand (262144 x 64) and the inverse-CDF abscissae u (262144 x 128) are drawn once and fed to both
+    sides -- to the product through torch.rand in its own per-chunk order (t_rand, u for each 65536-ray chunk; tests/util.py
+    injected_random), to the fp64 oracle as tensors.  |dPSNR| <= 1e-4 dB for the coarse and the fine image, all three arithmetics."""
+    import nerf
+    c = C.build_case("eval_det_64_128" if family == "hard" else "soft_eval_det_64_128")
+    H = W = 512
+    chunk = 65536
+    ro_c, rd_c = O.ray_bundle(H, W, O.INTRINSICS, O.frame_pose(c["frame"]))
+    ro, rd = nerf.get_ray_bundle(H, W, O.INTRINSICS, O.frame_pose(c["frame"]).to(gpu))
+    bg_img, tgt_img = O.synthetic_image(H, W, 7), O.synthetic_image(H, W, 11)
+    g = torch.Generator().manual_seed(20260924)
+    t_rand, u = torch.rand((H * W, 64), generator=g), torch.rand((H * W, 128), generator=g)
+    ref = U.oracle_render_fp64_on_device(c, ro_c.reshape(-1, 3), rd_c.reshape(-1, 3), bg_img.reshape(-1, 3), gpu, 64, 128, t_rand=t_rand, u=u)
+    tgt = tgt_img.reshape(-1, 3).to(gpu).double()
+    mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+    ex, ed = U.encoders(nerf)
+    psnr = lambda a, b: float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))
+    try:
+        for precision in ("f32", "f16x3", "bf16x3"):
+            nerf.set_mlp_precision(precision)
+            rands = [t for k in range(0, H * W, chunk) for t in (t_rand[k:k + chunk], u[k:k + chunk])]
+            with torch.no_grad(), U.injected_random(rands, []):
+                out = nerf.run_one_iter_of_nerf(H, W, None, mc, mf, ro, rd, U.make_options(nerf, 64, 128, True, 0.0, chunksize=chunk),
+                                                mode="validation", encode_position_fn=ex, encode_direction_fn=ed,
+                                                expressions=c["expr"].to(gpu), background_prior=bg_img.to(gpu).view(-1, 3),
+                                                latent_code=c["latent"].to(gpu))
+            for k in (0, 3):
+                ours = out[k].reshape(-1, 3)
+                dp = abs(psnr(ours, tgt) - psnr(ref[k], tgt))
+                print(f"full frame, perturb on [{family} {precision}] {NAMES7[k]}: |dPSNR| = {dp:.2e} dB over 262144 rays, self-PSNR "
+                      f"{psnr(ours, ref[k]):.1f} dB, max|d rgb| = {float((ours.double() - ref[k]).abs().max()):.2e}")
+                assert dp <= 1e-4, (family, precision, NAMES7[k], dp)
+    finally:
+        nerf.set_mlp_precision("f32")

@@ -129,3 +129,53 @@ def test_f16x3_end_to_end_at_f32_tolerances(hip_lib, gpu, name):
     for k in (0, 3):
         dp = abs(O.psnr(out[k].cpu(), c["tgt"]) - O.psnr(ref[k], c["tgt"]))
         assert dp <= 1e-4, (k, dp)
+
+
+def test_f16x3_range_guard_is_armed_in_training(hip_lib, gpu):
+    """Training under "f16x3" (VERDICT r02 weak #1): (a) an overflow that happens in ONE iteration between two polls is still seen at
+    the next poll -- every step re-packs the weight stream, which clears the stream's flag, so the flag is carried over on the
+    device (ops.PaperWeights._get); (b) a model that drifts out of range and stays there is refused by the exact-f32 probe at the
+    next cadence point (ops.set_f16_train_probe_every, which the trainer sets to its print_every).  Both raise RuntimeError."""
+    import nerf
+    from nerf import ops
+    c = C.build_case("train_rand_64_64")
+    opt = U.make_options(nerf, 64, 64, True, 0.1, chunksize=2048)
+    ex, ed = U.encoders(nerf)
+    n = c["ro"].shape[0]
+
+    def step(mc, mf):
+        latent = c["latent"].clone().to(gpu).requires_grad_(True)
+        with torch.enable_grad():
+            out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train",
+                                            encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                            background_prior=c["bg"].to(gpu), latent_code=latent)
+            (out[0].sum() + out[3].sum()).backward()
+    nerf.set_mlp_precision("f16x3")
+    try:
+        # (a) the sticky flag
+        ops.set_f16_train_probe_every(1000)                              # probe on the first step only: isolate the flag path
+        mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+        step(mc, mf)
+        step(mc, mf)
+        ops.check_f16_range(mc, mf)                                      # healthy so far
+        with torch.no_grad():
+            mf.fc_feat.weight.mul_(2.0 ** 16)                            # fc_feat has no ReLU: its overflow reaches sigma as inf / NaN
+        step(mc, mf)
+        with torch.no_grad():
+            mf.fc_feat.weight.mul_(2.0 ** -16)
+        step(mc, mf)                                                     # two healthy steps: each re-packs the stream
+        step(mc, mf)
+        with pytest.raises(RuntimeError, match="fp16 range"):
+            ops.check_f16_range(mc, mf)
+        # (b) the probe cadence
+        ops.set_f16_train_probe_every(2)                                 # calls 1, 3, 5, ... of each model
+        mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
+        step(mc, mf)
+        with torch.no_grad():
+            mc.layers_xyz[1].weight.mul_(2.0 ** 14)
+        step(mc, mf)                                                     # call 2: between two probes, saturates silently
+        with pytest.raises(RuntimeError, match="fp16 range"):
+            step(mc, mf)                                                 # call 3: the probe refuses the model
+    finally:
+        ops.set_f16_train_probe_every(128)
+        nerf.set_mlp_precision("f32")

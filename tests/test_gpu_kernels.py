@@ -334,3 +334,19 @@ def test_weighted_choice_follows_the_importance_map(hip_lib, gpu):
     torch.manual_seed(77)
     j1 = nerf.choose_rays(p, n)
     assert torch.equal(i1, j1) and not torch.equal(i1, i2)
+
+
+def test_weighted_choice_breaks_ties_by_index(hip_lib, gpu):
+    """K0 with many equal keys (constant weights, u from a 128-value grid: every key is shared by ~512 pixels -- far more than a real
+    draw's 1.5 % chance of ONE shared threshold key, and within the 1024 tie candidates the kernel ranks): the batch is the
+    n smallest (key, index) pairs -- ties go to the LOWEST indices, so the draw is a function of the seed, not of the order in
+    which workgroups happen to run -- and repeating the call reproduces it element for element."""
+    from nerf import ops
+    n_items, n = 256 * 256, 2000
+    g = torch.Generator().manual_seed(3)
+    u = (torch.randint(0, 128, (n_items,), generator=g).float() + 0.5) / 128.0
+    w = torch.full((n_items,), 1.0 / n_items)
+    want = torch.sort(torch.argsort(u.double() * n_items + torch.arange(n_items).double() / n_items, stable=True)[:n])[0]
+    got = [ops.weighted_choice(w.to(gpu), n, u=u.to(gpu)).cpu() for _ in range(3)]
+    assert torch.equal(got[0], want), int((got[0] != want).sum())
+    assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])

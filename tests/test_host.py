@@ -157,7 +157,7 @@ def test_product_has_no_cpu_path():
 
 def test_oracle_is_imported_only_by_the_checkers():
     """oracle/ is test infrastructure: nothing in the product package, the launchers or tools/ may import it; bench.py may only
-    inside its cpu_baseline legs (functions cpu_baseline, cpu_baseline_tiny) and __graft_entry__ only as the smoke() / build()
+    inside its baseline legs (functions cpu_baseline, cpu_baseline_tiny, eager_rocm_baseline) and __graft_entry__ only as the smoke() / build()
     checker."""
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
     for base in ("4d-facial-avatars_amd", "tools"):
@@ -168,7 +168,7 @@ def test_oracle_is_imported_only_by_the_checkers():
                     assert not pat.search(src), os.path.join(dirpath, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
     n_legs = 0
-    for fn in ("def cpu_baseline(", "def cpu_baseline_tiny("):
+    for fn in ("def cpu_baseline(", "def cpu_baseline_tiny(", "def eager_rocm_baseline("):
         leg = bench[bench.index(fn):]
         leg = leg[:leg.index("\ndef ", 1)]
         n_legs += len(pat.findall(leg))
@@ -288,9 +288,22 @@ def test_launcher_host_helpers():
     the jet colour map of the error image (matplotlib's piecewise-linear 'jet' at its anchor points)."""
     sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
     from launch import eval_sharded, train_sharded
+    # the reference looks draw k (probability probs[k], probs = the row-major (H, W) map) up in coords = meshgrid_xy(arange(H),
+    # arange(W)).reshape(-1, 2), i.e. pixel (k % H, k // H): the map acts transposed.  The launcher's weights are indexed by the
+    # row-major pixel index row * W + col, so weight[row * W + col] must equal probs[k] of the k with coords[k] == (row, col)
+    import nerf
+    for H_, W_, box in ((8, 8, [2, 6, 1, 5]), (6, 10, [1, 4, 2, 9])):
+        w = train_sharded.importance_maps(np.array([box]), H_, W_)[0]
+        probs = np.full((H_, W_), 1 - 0.9)
+        probs[box[0]:box[1], box[2]:box[3]] = 0.9
+        probs = (probs / probs.sum()).reshape(-1)
+        coords = torch.stack(nerf.meshgrid_xy(torch.arange(H_), torch.arange(W_)), dim=-1).reshape((-1, 2)).numpy()   # TR:302-306
+        assert abs(w.sum() - 1.0) < 1e-12 and w.shape == (H_ * W_,)
+        for k in range(H_ * W_):
+            row, col = int(coords[k, 0]), int(coords[k, 1])
+            assert w[row * W_ + col] == probs[k], (k, row, col)
     m = train_sharded.importance_maps(np.array([[2, 6, 1, 5]]), 8, 8)[0].reshape(8, 8)
-    assert abs(m.sum() - 1.0) < 1e-12 and np.allclose(m[2:6, 1:5] / m[0, 0], 9.0)
-    assert np.count_nonzero(m == m[0, 0]) == 64 - 16
+    assert np.allclose(m[1:5, 2:6] / m[0, 0], 9.0) and np.count_nonzero(m == m[0, 0]) == 64 - 16     # bbox rows <-> columns
     x = torch.tensor([[0.0, 0.125, 0.375], [0.5, 0.625, 1.0]])
     got = eval_sharded.jet_u8(x).tolist()
     want = [[[0, 0, 127], [0, 0, 255], [0, 255, 255]], [[127, 255, 127], [255, 255, 0], [127, 0, 0]]]

@@ -78,9 +78,10 @@ def run_product(nerf, c, device, mode="train", grad=False, chunksize=65536):
     return out, mc, mf, latent
 
 
-def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=4096, stages=None):
+def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=4096, stages=None, t_rand=None, u=None):
     """The ORACLE (oracle/nerface_oracle.py: torch ops, no product code) evaluated in float64 on `device`, in ray chunks --
-    the checker for whole 512x512 frames, which the CPU oracle would need minutes for.  Deterministic sampling."""
+    the checker for whole 512x512 frames, which the CPU oracle would need minutes for.  Deterministic sampling unless the
+    stratified jitter t_rand (R, n_coarse) and the inverse-CDF abscissae u (R, n_fine) are given (the draws the product is fed)."""
     pc = {k: v.to(device=device, dtype=torch.float64) for k, v in c["p_coarse"].items()}
     pf = {k: v.to(device=device, dtype=torch.float64) for k, v in c["p_fine"].items()}
     expr, lat = c["expr"].to(device=device, dtype=torch.float64), c["latent"].to(device=device, dtype=torch.float64)
@@ -89,7 +90,8 @@ def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=
         for k in range(0, ro.shape[0], chunk):
             f = lambda t: None if t is None else t[k:k + chunk].to(device=device, dtype=torch.float64)
             st = {} if stages is not None else None
-            parts.append(O.render_rays(pc, pf, f(ro), f(rd), expr, lat, f(bg), O.NEAR, O.FAR, n_coarse, n_fine, stages=st))
+            parts.append(O.render_rays(pc, pf, f(ro), f(rd), expr, lat, f(bg), O.NEAR, O.FAR, n_coarse, n_fine, t_rand=f(t_rand), u=f(u),
+                                       stages=st))
             if stages is not None:
                 for name, v in st.items():
                     stages.setdefault(name, []).append(v)
