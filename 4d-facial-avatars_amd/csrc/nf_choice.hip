@@ -7,23 +7,25 @@
 // e_i = -log(1 - u_i).  The n smallest keys are found by an exact three-level radix select on the 32 key bits (12 + 12 + 8;
 // positive floats order like their bit patterns): each level is one launch that histograms the digit of the keys that match the
 // prefix found so far (LDS histogram per workgroup, merged with global atomics), and the LAST workgroup to finish scans the
-// 4096 bins, extends the prefix and clears the histogram for the next level.  A fourth launch emits the indices of every key below
-// the threshold (slots come from an atomic counter) and collects the items whose key EQUALS it; a one-workgroup kernel then takes
-// as many of those ties as are still missing -- the ones with the LOWEST indices, not the first to arrive (torch.rand has 24
-// random bits: on a 512 x 512 frame the threshold key is shared in ~1.5 % of the draws) -- and a one-workgroup bitonic sort puts the
-// batch in ascending order, so that a seed reproduces the batch element for element (the order of the rays decides the
-// summation order of the gradients downstream).  HBM-bound: 4 passes over 8 bytes per item (2 MB per pass for a
-// 512 x 512 frame, L2-resident).
+// 4096 bins, extends the prefix and clears the histogram for the next level.  Then an ORDERED compaction in two launches: every
+// workgroup counts, in its contiguous range of items, the keys below the threshold and the keys equal to it; the second launch
+// turns the counts of the workgroups before it into its output offset and writes its items in index order -- every key below the
+// threshold and, of the keys equal to it, the first `remaining` in index order (torch.rand has 24 random bits: on a 512 x 512 frame
+// the threshold key is shared in ~1.5 % of the draws).  The batch comes out ascending without a sort and is a function of the
+// seed alone (the order of the rays decides the summation order of the gradients downstream).  64 workgroups: the level passes
+// merge their histograms with global atomics on the few bins the keys populate, and 256 workgroups queued 256-deep on each of them
+// (25 us per level, more than the 2 MB the pass reads would take 8 times over).  HBM-bound in principle: 5 passes over 8 bytes per
+// item (2 MB per pass for a 512 x 512 frame, L2-resident); ~30 us per draw.
 #include "nf_common.h"
 
 #define NF_CHOICE_BINS 4096
-#define NF_CHOICE_MAX_TIES 1024   // tie candidates kept for the deterministic tie-break (more than that: the first to arrive)
+#define NF_CHOICE_MAX_BLOCKS 64
 struct NfChoiceState {            // workspace header (uint32 words): zeroed by the host-side memset before the first level
     unsigned done;                // workgroups that have flushed their histogram (reset by the scanning workgroup)
     unsigned prefix;              // key bits fixed so far
     unsigned remaining;           // how many keys of the current prefix class are still wanted
-    unsigned emitted;             // select pass: slots handed out to keys below the threshold
-    unsigned ties;                // select pass: keys equal to the threshold seen so far
+    unsigned emitted;             // (unused)
+    unsigned ties;                // (unused)
     unsigned short_of;            // != 0: fewer than n items with a positive weight (np.random.choice raises ValueError there)
     unsigned pad[2];
 };
@@ -49,9 +51,17 @@ __global__ void __launch_bounds__(256) k_choice_level(const float* __restrict__ 
     for (int b = threadIdx.x; b < (int)DIGITS; b += 256) lh[b] = 0;
     __syncthreads();
     const unsigned prefix = LEVEL == 0 ? 0u : st->prefix;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
-        const unsigned k = nf_choice_key(w, u, i);
-        if (LEVEL == 0 || (k & HIGH_MASK) == prefix) atomicAdd(&lh[(k >> SHIFT) & (DIGITS - 1)], 1u);
+    // four items per thread and trip: 64 workgroups leave one wave per SIMD, so the loads' latency has to be covered by the thread itself
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 1024) {
+        unsigned k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int64_t j = i + (int64_t)q * gridDim.x * 256;
+            k[q] = j < n_items ? nf_choice_key(w, u, j) : 0xffffffffu;       // (past the end: matches no prefix, no level-0 digit below)
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            if (k[q] != 0xffffffffu && (LEVEL == 0 || (k[q] & HIGH_MASK) == prefix)) atomicAdd(&lh[(k[q] >> SHIFT) & (DIGITS - 1)], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < (int)DIGITS; b += 256)
@@ -104,60 +114,97 @@ __global__ void __launch_bounds__(256) k_choice_level(const float* __restrict__ 
     if (threadIdx.x == 0) st->done = 0;
 }
 
-__global__ void __launch_bounds__(256) k_choice_select(const float* __restrict__ w, const float* __restrict__ u, int64_t n_items, int n_select,
-                                                       NfChoiceState* __restrict__ st, int64_t* __restrict__ tie_buf, int64_t* __restrict__ idx_out) {
-    const unsigned thr = st->prefix;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_items; i += (int64_t)gridDim.x * 256) {
-        const unsigned k = nf_choice_key(w, u, i);
-        if (k == 0x7f800000u) continue;                             // weight 0
-        if (k < thr) {
-            const unsigned slot = atomicAdd(&st->emitted, 1u);
-            if (slot < (unsigned)n_select) idx_out[slot] = i;
-        } else if (k == thr) {
-            const unsigned t = atomicAdd(&st->ties, 1u);
-            if (t < NF_CHOICE_MAX_TIES) tie_buf[t] = i;
-        }
-    }
+// contiguous item range of a workgroup (the same in both compaction kernels)
+__device__ __forceinline__ void nf_choice_range(int64_t n_items, int64_t& i0, int64_t& i1) {
+    const int64_t span = ((n_items + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    i0 = (int64_t)blockIdx.x * span;
+    i1 = i0 + span < n_items ? i0 + span : n_items;
 }
 
-// the `remaining` lowest-indexed ties fill the slots behind the keys below the threshold (rank by counting: the list is short)
-__global__ void __launch_bounds__(256) k_choice_ties(int n_select, const NfChoiceState* __restrict__ st, const int64_t* __restrict__ tie_buf,
-                                                     int64_t* __restrict__ idx_out) {
-    const unsigned n_t = st->ties < NF_CHOICE_MAX_TIES ? st->ties : NF_CHOICE_MAX_TIES;
-    const unsigned wanted = st->remaining, base = st->emitted;
-    for (unsigned a = threadIdx.x; a < n_t; a += 256) {
-        const int64_t mine = tie_buf[a];
-        unsigned rank = 0;
-        for (unsigned b = 0; b < n_t; ++b) rank += tie_buf[b] < mine ? 1u : 0u;
-        if (rank < wanted && base + rank < (unsigned)n_select) idx_out[base + rank] = mine;
-    }
-}
-
-// ascending order, unsigned compare (the -1 fillers of a short draw go last); n <= NF_CHOICE_SORT_MAX, one workgroup
-#define NF_CHOICE_SORT_MAX 8192
-__global__ void __launch_bounds__(1024) k_choice_sort(int64_t* __restrict__ idx, int n) {
-    __shared__ uint64_t v[NF_CHOICE_SORT_MAX];
-    int m = 1;
-    while (m < n) m <<= 1;
-    for (int i = threadIdx.x; i < m; i += 1024) v[i] = i < n ? (uint64_t)idx[i] : ~0ull;
+// per workgroup: how many keys of its range lie below the threshold / equal it
+__global__ void __launch_bounds__(256) k_choice_count(const float* __restrict__ w, const float* __restrict__ u, int64_t n_items,
+                                                      const NfChoiceState* __restrict__ st, unsigned* __restrict__ counts) {
+    __shared__ unsigned s_lt, s_eq;
+    if (threadIdx.x == 0) s_lt = s_eq = 0u;
     __syncthreads();
-    for (int k = 2; k <= m; k <<= 1)
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < m; i += 1024) {
-                const int p = i ^ j;
-                if (p > i) {
-                    const uint64_t a = v[i], b = v[p];
-                    const bool up = (i & k) == 0;
-                    if ((a > b) == up) { v[i] = b; v[p] = a; }
-                }
-            }
-            __syncthreads();
+    const unsigned thr = st->prefix;
+    int64_t i0, i1;
+    nf_choice_range(n_items, i0, i1);
+    unsigned lt = 0, eq = 0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 1024) {
+        unsigned k[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) k[q] = i + 256 * q < i1 ? nf_choice_key(w, u, i + 256 * q) : 0x7f800000u;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (k[q] == 0x7f800000u) continue;                      // weight 0 (or past the range)
+            lt += k[q] < thr ? 1u : 0u;
+            eq += k[q] == thr ? 1u : 0u;
         }
-    for (int i = threadIdx.x; i < n; i += 1024) idx[i] = (int64_t)v[i];
+    }
+    for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); eq += __shfl_xor(eq, o, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&s_lt, lt); atomicAdd(&s_eq, eq); }
+    __syncthreads();
+    if (threadIdx.x == 0) { counts[2 * blockIdx.x] = s_lt; counts[2 * blockIdx.x + 1] = s_eq; }
+}
+
+// per workgroup: offsets from the counts of the workgroups before it, then its items in index order
+__global__ void __launch_bounds__(256) k_choice_emit(const float* __restrict__ w, const float* __restrict__ u, int64_t n_items, int n_select,
+                                                     const NfChoiceState* __restrict__ st, const unsigned* __restrict__ counts,
+                                                     int64_t* __restrict__ idx_out) {
+    __shared__ unsigned s_wave[2][4], s_base[2];
+    const unsigned thr = st->prefix, ties_wanted = st->remaining;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x < 64) {                                         // keys below / equal to the threshold in the workgroups before this one
+        unsigned lt = 0, eq = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) { lt += counts[2 * b]; eq += counts[2 * b + 1]; }
+        for (int o = 32; o > 0; o >>= 1) { lt += __shfl_xor(lt, o, 64); eq += __shfl_xor(eq, o, 64); }
+        if (lane == 0) { s_base[0] = lt; s_base[1] = eq; }
+    }
+    __syncthreads();
+    unsigned lt_before = s_base[0], eq_before = s_base[1];
+    int64_t i0, i1;
+    nf_choice_range(n_items, i0, i1);
+    for (int64_t t4 = i0; t4 < i1; t4 += 1024) {                    // keys of four 256-item tiles at a time (latency), tiles in order
+      unsigned k4[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+          const int64_t j = t4 + 256 * q + threadIdx.x;
+          k4[q] = j < i1 ? nf_choice_key(w, u, j) : 0x7f800000u;
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int64_t t0 = t4 + 256 * q;
+        if (t0 >= i1) break;                                        // (uniform)
+        const int64_t i = t0 + threadIdx.x;
+        const unsigned k = k4[q];
+        const bool lt = k < thr && k != 0x7f800000u, eq = k == thr && k != 0x7f800000u;
+        const unsigned long long m_lt = __ballot(lt), m_eq = __ballot(eq);
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (lane == 0) { s_wave[0][wave] = (unsigned)__popcll(m_lt); s_wave[1][wave] = (unsigned)__popcll(m_eq); }
+        __syncthreads();
+        unsigned lt_w = 0, eq_w = 0, lt_all = 0, eq_all = 0;
+        for (int q = 0; q < 4; ++q) {
+            if (q < wave) { lt_w += s_wave[0][q]; eq_w += s_wave[1][q]; }
+            lt_all += s_wave[0][q];
+            eq_all += s_wave[1][q];
+        }
+        const unsigned my_lt = lt_before + lt_w + (unsigned)__popcll(m_lt & below);       // taken keys below the threshold with a smaller index
+        const unsigned my_eq = eq_before + eq_w + (unsigned)__popcll(m_eq & below);       // ties with a smaller index
+        const unsigned ties_taken_before = my_eq < ties_wanted ? my_eq : ties_wanted;
+        if (lt || (eq && my_eq < ties_wanted)) {
+            const unsigned slot = my_lt + ties_taken_before;
+            if (slot < (unsigned)n_select) idx_out[slot] = i;
+        }
+        lt_before += lt_all;
+        eq_before += eq_all;
+        __syncthreads();
+      }
+    }
 }
 
 extern "C" size_t nf_weighted_choice_workspace_bytes(void) {
-    return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned) + NF_CHOICE_MAX_TIES * sizeof(int64_t);
+    return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned) + 2 * NF_CHOICE_MAX_BLOCKS * sizeof(unsigned);
 }
 
 extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t n_items, int n_select, int64_t* idx_out, void* workspace,
@@ -173,15 +220,13 @@ extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t 
     if (e != hipSuccess) return (int)e;
     NfChoiceState* st = reinterpret_cast<NfChoiceState*>(workspace);
     unsigned* hist = reinterpret_cast<unsigned*>(st + 1);
-    int64_t* tie_buf = reinterpret_cast<int64_t*>(hist + NF_CHOICE_BINS);
+    unsigned* counts = hist + NF_CHOICE_BINS;
     const int64_t want = (n_items + 255) / 256;
-    const int grid = (int)(want < 256 ? want : 256);
+    const int grid = (int)(want < NF_CHOICE_MAX_BLOCKS ? want : NF_CHOICE_MAX_BLOCKS);
     hipLaunchKernelGGL(k_choice_level<0>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<1>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<2>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
-    hipLaunchKernelGGL(k_choice_select, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, tie_buf, idx_out);
-    hipLaunchKernelGGL(k_choice_ties, dim3(1), dim3(256), 0, s, n_select, st, tie_buf, idx_out);
-    if (n_select <= NF_CHOICE_SORT_MAX)                              // larger draws stay in slot order (the Python wrapper sorts them)
-        hipLaunchKernelGGL(k_choice_sort, dim3(1), dim3(1024), 0, s, idx_out, n_select);
+    hipLaunchKernelGGL(k_choice_count, dim3(grid), dim3(256), 0, s, weights, u, n_items, st, counts);
+    hipLaunchKernelGGL(k_choice_emit, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, counts, idx_out);
     NF_RETURN_LAUNCH();
 }

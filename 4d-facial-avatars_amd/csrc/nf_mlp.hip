@@ -324,9 +324,15 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
 
     f32x4 acc[NT][16];
     uint2 m[NT];
+#ifdef NF_ABL_NOMASK
+    constexpr bool NF_ABL_NOMASK_ = true;
+#else
+    constexpr bool NF_ABL_NOMASK_ = false;
+#endif
 #define NF_FINISH_SAVE(NO_, MASKL_)                                                                  \
     do {                                                                                            \
-        if ((MASKL_) >= 0) {                                                                        \
+        if (NF_ABL_NOMASK_ && (MASKL_) >= 0) nf_relu_inplace<NT, NO_>(acc);                         \
+        else if ((MASKL_) >= 0) {                                                                   \
             nf_relu_with_mask<NT, NO_>(acc, m);                                                     \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
                 if (p0 + 16 * t < n) *nf_mask_ptr(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t];    \

@@ -470,8 +470,17 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    NfReduceAlt alt;
+    alt.n_slices = 0;
+    for (int q = 0; q < NF_REDUCE_ALT_MAX; ++q) alt.lo4[q] = alt.hi4[q] = 0;
+    // the slabs are fully written by the GEMM kernel -- except, in the shared-panel plan, by the group that runs fewer slices: the
+    // reduction is told which regions end early instead of a 71 MB zero-fill per call
+    const bool lds_plan = !split_dw && !nf_legacy_train();
+    if (!(lds_plan && nf_dw_reduce_alt(gset.g, NF_DW_GROUPS, ns, &alt))) {
+        alt.n_slices = 0;
+        e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};          // stage_ms: dX chain | weight-gradient GEMMs | reduce + unpack
     auto mark = [&](int k) {
         if (stage_ms && hipEventCreate(&ev[k]) == hipSuccess) (void)hipEventRecord(ev[k], s);
@@ -510,11 +519,11 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
         }
     }
     mark(2);
-    hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
+    hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, alt);
     NfGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];
-    hipLaunchKernelGGL(k_paper_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
+    hipLaunchKernelGGL(k_paper_grad_unpack, dim3((GRAD_FLOATS + 255) / 256), dim3(256), 0, s, sum, packed, cond, offs, grads);   // one element per thread: the kernel is a dependent search + gather, i.e. latency
     if (stage_ms) {
         mark(3);
         e = hipStreamSynchronize(s);

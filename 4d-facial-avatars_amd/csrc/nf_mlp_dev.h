@@ -263,7 +263,13 @@ template <int W4>
 __device__ __forceinline__ void nf_copy_write(const f32x4 v, const NfSlabCopy& cp, int inst, int lane) {
     constexpr int RPI = 64 / W4;
     const int p = inst * RPI + lane / W4, q = lane % W4;
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, 0);
+    // aux 2 = nt (non-temporal): the 9 KB per point stream to HBM and are not read back before the weight-gradient kernel; as ordinary
+    // write-back stores they pushed the 2 MB weight image out of L2 and delayed the in-order vmcnt of the weight loads behind them
+    // (forward 2.224 -> 2.184 ms, chain 1.972 -> 1.940 ms per 262144-point launch, profiles/r03_experiments.md)
+#ifndef NF_COPY_AUX
+#define NF_COPY_AUX 2
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, NF_COPY_AUX);
 }
 template <int W4>
 __device__ __forceinline__ void nf_copy_rows(const f32x4* act4, const NfSlabCopy& cp, int inst, int lane) {
@@ -285,8 +291,10 @@ struct NfCopySide {
         for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, k, lane);
     }
     __device__ __forceinline__ void half1(int it) const {
+#ifndef NF_ABL_NOCOPY
 #pragma unroll
         for (int k = 0; k < PER; ++k) nf_copy_write<W4>(cv[k], cp, it * PER + k, lane);
+#endif
     }
     __device__ __forceinline__ void half2(int it) {                      // past the last iteration: re-read its rows (unused)
         const int nx = it + 1 < n_it ? it + 1 : it;

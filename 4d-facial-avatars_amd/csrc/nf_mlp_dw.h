@@ -189,6 +189,38 @@ static inline int nf_dw_plan_groups(NfDwGroup* g, int n_groups, int64_t n_points
     return most;
 }
 
+#define NF_REDUCE_ALT_MAX 8
+struct NfReduceAlt {
+    int lo4[NF_REDUCE_ALT_MAX], hi4[NF_REDUCE_ALT_MAX];
+    int n_slices;        // 0: no such regions
+};
+// Slab regions of the groups that run fewer slices than `most` (their products fill only the first n_slices slabs).  Requires such a
+// group's outputs to be whole rows (ldo == k_valid) -- true for the products against the positional encoding.  Returns false if the
+// plan cannot be expressed (then the caller zero-fills the slabs instead).
+static inline bool nf_dw_reduce_alt(const NfDwGroup* g, int n_groups, int most, NfReduceAlt* alt) {
+    int n = 0;
+    alt->n_slices = 0;
+    for (int q = 0; q < NF_REDUCE_ALT_MAX; ++q) alt->lo4[q] = alt->hi4[q] = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        if (g[i].n_slices == most) continue;
+        if (alt->n_slices && alt->n_slices != g[i].n_slices) return false;
+        alt->n_slices = g[i].n_slices;
+        for (int w = 0; w < 4; ++w) {
+            const NfDwWaveJob& j = g[i].wave[w];
+            if (j.ldo != j.k_valid || (j.out_off & 3) || ((j.n_valid * j.ldo) & 3)) return false;
+            if (n + 2 > NF_REDUCE_ALT_MAX) return false;
+            alt->lo4[n] = j.out_off >> 2;
+            alt->hi4[n++] = (j.out_off + j.n_valid * j.ldo) >> 2;
+            if (j.cs_off >= 0) {
+                if ((j.cs_off & 3) || (j.n_valid & 3)) return false;
+                alt->lo4[n] = j.cs_off >> 2;
+                alt->hi4[n++] = (j.cs_off + j.n_valid) >> 2;
+            }
+        }
+    }
+    return true;
+}
+
 __device__ __attribute__((aligned(16))) static const float nf_dw_zero16[4] = {0.f, 0.f, 0.f, 0.f};
 
 template <int N> __device__ __forceinline__ void nf_dw_wait_vm_lgkm0() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
@@ -300,25 +332,47 @@ k_dw_gemm_lds(NfDwGroupSet gs, int slab_floats, const float* __restrict__ dz, co
             const bool adv = c + 4 < n_full;
             if (active) {
                 __builtin_amdgcn_sched_barrier(0);
+                // Four steps, fenced from one another (sched_barrier) so that the requested order is local and exact: 16 MFMAs,
+                // a DMA piece of chunk c + 3 (-> the stage chunk c left), 16 MFMAs, a second piece, then the refill of the step's
+                // 3 operand registers from chunk c + 1 -- issued right behind the MFMAs that read them.  The LAST step's refill
+                // would sit right in front of the barrier (its LDS round trip in the path of all eight waves): it is read early, into
+                // three staging registers behind step 0, and moved over after step 3's MFMAs.
+#ifndef NF_DW_NO_STAGGER
+                // The two waves of a SIMD (the halves of one product) run this stream side by side, and a DMA piece holds its wave's
+                // issue for ~100 cycles: half 1 starts every chunk 8 MFMA slots late (its partner has the pipe to itself meanwhile).
+#ifndef NF_DW_STAGGER_SLEEP
+#define NF_DW_STAGGER_SLEEP 4                                        // x 64 cycles
+#endif
+                if (half) __builtin_amdgcn_s_sleep(NF_DW_STAGGER_SLEEP);
+#endif
                 if (want_cs) {   // column sums of this chunk's A operands (bias gradients), before the refills overwrite them
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { cs[0] += a0[r][0]; cs[1] += a0[r][1]; }
                 }
-                // Four steps, fenced from one another (sched_barrier) so that the requested order is local and exact: 16 MFMAs,
-                // a DMA piece of chunk c + 3 (-> the stage chunk c left), 16 MFMAs, a second piece, then the refill of the step's
-                // 3 operand registers from chunk c + 1 -- issued right behind the MFMAs that read them.
+                f32x4 a3s[2], b3s;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     mma_step(r);
                     if (r < 3) { issue_piece(2 * r, st, adv); issue_piece(2 * r + 1, st, adv); }
-                    read_step(s1, r);                                // (after the last chunk: reads a stage nobody uses)
+                    if (r < 3) read_step(s1, r);                     // (after the last chunk: reads a stage nobody uses)
+                    if (r == 0) {
+                        const char* sa = lds + s1 * NF_DW_STAGE_BYTES + job.a * NF_DW_PANEL_BYTES + lane_off + 3 * 2048;
+                        const char* sb = lds + s1 * NF_DW_STAGE_BYTES + job.b * NF_DW_PANEL_BYTES + half * 256 + lane_off + 3 * 2048;
+                        a3s[0] = *reinterpret_cast<const f32x4*>(sa);
+                        a3s[1] = *reinterpret_cast<const f32x4*>(sa + 256);
+                        b3s = *reinterpret_cast<const f32x4*>(sb);
+                    }
                     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                     if (r < 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
                     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
                     if (r < 3) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+                    if (r == 0) __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);
+                    else if (r < 3) __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
+                a0[3][0] = a3s[0];
+                a0[3][1] = a3s[1];
+                b0[3] = b3s;
             } else {
                 issue(st, adv);                                      // an idle half only moves data
             }
@@ -383,20 +437,29 @@ k_dw_gemm_lds(NfDwGroupSet gs, int slab_floats, const float* __restrict__ dz, co
 
 // B3, first half: sum the per-slice slabs in a fixed order (deterministic).  16 bytes per thread, four independent partial
 // sums (slices k = 0, 1, 2, 3 mod 4) so that the loads of consecutive slices overlap; slab_floats is a multiple of 4.
+// `alt`: slab regions (float4 units) that only the first alt.n_slices slabs hold -- the products of a group that runs fewer,
+// longer slices (nf_dw_plan_groups) -- so that the slabs need no zero-fill (71 MB per backward call) before the GEMM kernel.
 template <int MODEL>
-__global__ void __launch_bounds__(256) k_grad_reduce(const float* __restrict__ slabs, int n_slices, int slab_floats, float* __restrict__ sum) {
+__global__ void __launch_bounds__(256) k_grad_reduce(const float* __restrict__ slabs, int n_slices, int slab_floats, float* __restrict__ sum,
+                                                     NfReduceAlt alt) {
     const int n4 = slab_floats >> 2;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n4; e += gridDim.x * blockDim.x) {
         const f32x4* src = reinterpret_cast<const f32x4*>(slabs) + e;
+        int ns = n_slices;
+        if (alt.n_slices > 0) {
+#pragma unroll
+            for (int q = 0; q < NF_REDUCE_ALT_MAX; ++q)
+                if (e >= alt.lo4[q] && e < alt.hi4[q]) ns = alt.n_slices;
+        }
         f32x4 a[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) a[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
         int k = 0;
-        for (; k + 4 <= n_slices; k += 4) {
+        for (; k + 4 <= ns; k += 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] += src[(int64_t)(k + q) * n4];
         }
-        for (; k < n_slices; ++k) a[k & 3] += src[(int64_t)k * n4];
+        for (; k < ns; ++k) a[k & 3] += src[(int64_t)k * n4];
         reinterpret_cast<f32x4*>(sum)[e] = (a[0] + a[1]) + (a[2] + a[3]);
     }
 }

@@ -289,7 +289,7 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
         hipLaunchKernelGGL((k_dw_gemm<1>), dim3((NF_LC_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_LC_DW_JOBS, (int)SLAB_FLOATS, dz,
                            d_raw, saved, n_points, pps, slabs);
     }
-    hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum);
+    hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, NfReduceAlt{});
     NfLcodeGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NPARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_LC_PARAM_NUMEL[i];

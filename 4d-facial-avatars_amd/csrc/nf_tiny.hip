@@ -280,7 +280,7 @@ extern "C" int nf_tiny_mlp_bwd(const float* packed_t, const float* saved, const 
     hipLaunchKernelGGL((k_tiny_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);
     hipLaunchKernelGGL((k_dw_gemm<2>), dim3((N_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, (int)N_JOBS, (int)SLAB, dz, d_raw, saved, n_points,
                        pps, slabs);
-    hipLaunchKernelGGL((k_grad_reduce<2>), dim3(64), dim3(256), 0, s, slabs, ns, (int)SLAB, sum);
+    hipLaunchKernelGGL((k_grad_reduce<2>), dim3(64), dim3(256), 0, s, slabs, ns, (int)SLAB, sum, NfReduceAlt{});
     hipLaunchKernelGGL(k_tiny_grad_unpack, dim3(64), dim3(256), 0, s, sum, grads);
     NF_RETURN_LAUNCH();
 }

@@ -115,8 +115,6 @@ def weighted_choice(weights: torch.Tensor, n: int, u: Optional[torch.Tensor] = N
                 "nf_weighted_choice")
     if check and n > 0 and int(ws[5].item()):
         raise ValueError("Fewer non-zero entries in p than size")
-    if n > 8192:                                          # the in-kernel sort covers the trainer's batch sizes
-        idx = torch.sort(idx)[0]
     return idx
 
 

@@ -338,7 +338,7 @@ def test_weighted_choice_follows_the_importance_map(hip_lib, gpu):
 
 def test_weighted_choice_breaks_ties_by_index(hip_lib, gpu):
     """K0 with many equal keys (constant weights, u from a 128-value grid: every key is shared by ~512 pixels -- far more than a real
-    draw's 1.5 % chance of ONE shared threshold key, and within the 1024 tie candidates the kernel ranks): the batch is the
+    draw's 1.5 % chance of ONE shared threshold key): the batch is the
     n smallest (key, index) pairs -- ties go to the LOWEST indices, so the draw is a function of the seed, not of the order in
     which workgroups happen to run -- and repeating the call reproduces it element for element."""
     from nerf import ops
