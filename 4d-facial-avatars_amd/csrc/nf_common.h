@@ -15,8 +15,6 @@
 
 static inline hipStream_t nf_s(nf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-extern int g_nf_legacy_train;                         // nf_lib.hip: A/B switch of the exact-f32 training kernels
-static inline bool nf_legacy_train() { return g_nf_legacy_train != 0; }
 
 // IEEE single ops that must not be contracted into FMAs (bit parity with the reference's
 // separate mul / add tensor ops).  The library is also built with -ffp-contract=off.

@@ -170,13 +170,11 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // =================================================================================================
 // forward
 // =================================================================================================
-// SAVE = training forward: every layer output is also written to the `saved` buffer (layout nfl::S_*),
-// from which the backward chain takes its ReLU masks and the weight-gradient GEMMs their right operands.
-template <int NT, bool SAVE>
+template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z,
-                int64_t n_points, int S, float* __restrict__ raw, float* __restrict__ saved) {
+                int64_t n_points, int S, float* __restrict__ raw) {
     using namespace nfl;
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -203,11 +201,6 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
-        if (SAVE && p0 + 16 * t + c < n_points) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(saved + S_PE * n_points + p * 64 + 16 * j + 4 * g) = pe[t][j];
-            *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
-        }
     }
 
     f32x4 acc[NT][16];
@@ -215,7 +208,6 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     do {                                                                                            \
         if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                   \
         nf_store_act<NT, NO_, false>(acc, act4, lane);                                              \
-        if (SAVE) nf_store_global<NT, NO_>(acc, saved + (int64_t)(SEC_) * n_points, WIDTH_, p0, n_points, lane); \
     } while (0)
     // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
     nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
@@ -324,15 +316,9 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
 
     f32x4 acc[NT][16];
     uint2 m[NT];
-#ifdef NF_ABL_NOMASK
-    constexpr bool NF_ABL_NOMASK_ = true;
-#else
-    constexpr bool NF_ABL_NOMASK_ = false;
-#endif
 #define NF_FINISH_SAVE(NO_, MASKL_)                                                                  \
     do {                                                                                            \
-        if (NF_ABL_NOMASK_ && (MASKL_) >= 0) nf_relu_inplace<NT, NO_>(acc);                         \
-        else if ((MASKL_) >= 0) {                                                                   \
+        if ((MASKL_) >= 0) {                                                                        \
             nf_relu_with_mask<NT, NO_>(acc, m);                                                     \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
                 if (p0 + 16 * t < n) *nf_mask_ptr(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t];    \
@@ -406,15 +392,12 @@ static int nf_launch_fwd(const float* packed, const float* cond, const float* ro
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
     if (saved && n_points >= ((int64_t)1 << 22)) return NF_EINVAL;       // the save path addresses a section with 32-bit byte offsets (1 KiB per point)
-    if (saved && !nf_legacy_train())
+    if (saved)
         hipLaunchKernelGGL((k_paper_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
-    else if (saved)
-        hipLaunchKernelGGL((k_paper_mlp_fwd<NT, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
-                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
-        hipLaunchKernelGGL((k_paper_mlp_fwd<NT, false>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
-                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, (float*)nullptr);
+        hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
     NF_RETURN_LAUNCH();
 }
 

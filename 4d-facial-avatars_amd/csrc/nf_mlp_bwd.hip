@@ -64,76 +64,9 @@ extern "C" int nf_paper_pack_bwd(const float* const* params, float* packed_t, nf
 // =================================================================================================
 // B1: backward chain
 // =================================================================================================
-template <int NT>
-__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
-k_paper_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
-                      int64_t n_points, float* __restrict__ dz) {
-    using namespace nfl;
-    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int g = lane >> 4, c = lane & 15;
-    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
-    if (p0 >= n_points) return;
-    f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
-    const int64_t n = n_points;
-
-    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int64_t p = p0 + 16 * t + c;
-        f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
-        if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
-        frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
-        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
-    }
-    f32x4 acc[NT][16];
-#define NF_BWD_FINISH(NO_, MASKSEC_, MASKW_, ZSEC_)                                                     \
-    do {                                                                                                \
-        if ((MASKSEC_) >= 0) nf_mask_by_saved<NT, NO_>(acc, saved + (int64_t)(MASKSEC_) * n, MASKW_, p0, n, lane); \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
-        nf_store_global<NT, NO_>(acc, dz + (int64_t)(ZSEC_) * n, (NO_) * 16, p0, n, lane);              \
-    } while (0)
-    // d(layers_dir.2 out) = d rgb . fc_rgb.weight ; mask by layers_dir.2's ReLU
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
-    NF_BWD_FINISH(8, S_D2, 128, Z_D2);
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_lds<NT, 8>(acc, WT + OFFT_D2 / 4, 8, act4, lane);
-    NF_BWD_FINISH(8, S_D1, 128, Z_D1);
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_lds<NT, 8>(acc, WT + OFFT_D1 / 4, 8, act4, lane);
-    NF_BWD_FINISH(8, S_D0, 128, Z_D0);
-    // d feat = dZ_D0 . layers_dir.0.weight[:, :256] + d sigma * fc_alpha.weight   (no activation on feat)
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_D0 / 4, 8, act4, lane);
-    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_D0 / 4 + 8 * 16 * 64, frag_sig, lane);
-    NF_BWD_FINISH(16, -1, 256, Z_FEAT);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_FEAT / 4, 16, act4, lane);
-    NF_BWD_FINISH(16, S_H5, 256, Z_L5);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L5 / 4, 16, act4, lane);
-    NF_BWD_FINISH(16, S_H4, 256, Z_L4);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L4 / 4, 16, act4, lane);
-    NF_BWD_FINISH(16, S_H3, 256, Z_L3);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L3 / 4, 16, act4, lane);     // hidden columns of the skip layer only
-    NF_BWD_FINISH(16, S_H2, 256, Z_L2);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L2 / 4, 16, act4, lane);
-    NF_BWD_FINISH(16, S_H1, 256, Z_L1);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_L1 / 4, 16, act4, lane);
-    NF_BWD_FINISH(16, S_H0, 256, Z_L0);
-#undef NF_BWD_FINISH
-}
-
-// The chain as shipped: ReLU masks come from the bit masks the training forward left in section S_MASK (288 bytes per
-// point, all nine layers fetched at kernel entry) instead of 7.7 KB per point of saved activations read synchronously at
-// every layer boundary, and every dZ section leaves through the wave's LDS slab as whole lines, from inside the next
-// layer's K loop (nf_mma_from_lds_copy) -- see nf_mlp_dev.h.  Arithmetic and results are those of k_paper_mlp_bwd_chain.
+// ReLU masks come from the bit masks the training forward left in section S_MASK (288 bytes per point, all nine layers fetched
+// at kernel entry) -- round 2 read 7.7 KB per point of saved activations synchronously at every layer boundary -- and every dZ
+// section leaves through the wave's LDS slab as whole lines, from inside the next layer's K loop (nf_mma_from_lds_copy, nf_mlp_dev.h).
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_paper_mlp_bwd_chain_masks(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
@@ -215,42 +148,7 @@ k_paper_mlp_bwd_chain_masks(const float* __restrict__ packed_t, const float* __r
 // =================================================================================================
 // B2: weight-gradient GEMMs (generic kernel in nf_mlp_dw.h); the paper model's job table
 // =================================================================================================
-#define NF_DW_JOBS 36
-
-static void nf_build_dw_jobs(NfDwJob* j) {
-    using namespace nfl;
-    int n = 0;
-    auto add = [&](int a_kind, int a_sec, int lda, int a_col0, int n_valid, int b_sec, int ldb, int b_col0, int k_valid,
-                   int out_off, int ldo, int cs_off) {
-        j[n++] = NfDwJob{a_kind, a_sec, lda, a_col0, n_valid, b_sec, ldb, b_col0, k_valid, out_off, ldo, cs_off};
-    };
-    // a full 256 x K layer: n-blocks {0,1} x k-blocks
-    auto layer256 = [&](int zsec, int bsec, int ldb, int kdim, int gout, int cs) {
-        for (int nb = 0; nb < 2; ++nb)
-            for (int kb = 0; kb * 128 < kdim; ++kb)
-                add(0, zsec, 256, 128 * nb, 128, bsec, ldb, 128 * kb, kdim - 128 * kb < 128 ? kdim - 128 * kb : 128,
-                    gout + 128 * nb * kdim + 128 * kb, kdim, (kb == 0 && cs >= 0) ? cs + 128 * nb : -1);
-    };
-    layer256(Z_L0, S_PE, 64, 64, G_L0, CS_L0 + 0);
-    layer256(Z_L1, S_H0, 256, 256, G_L1, CS_L0 + 256);
-    layer256(Z_L2, S_H1, 256, 256, G_L2, CS_L0 + 512);
-    layer256(Z_L3, S_PE, 64, 64, G_L3A, CS_L0 + 768);
-    layer256(Z_L3, S_H2, 256, 256, G_L3B, -1);
-    layer256(Z_L4, S_H3, 256, 256, G_L4, CS_L0 + 1024);
-    layer256(Z_L5, S_H4, 256, 256, G_L5, CS_L0 + 1280);
-    layer256(Z_FEAT, S_H5, 256, 256, G_FEAT, CS_L0 + 1536);
-    add(0, Z_D0, 128, 0, 128, S_FEAT, 256, 0, 128, G_D0A, 256, CS_D0);
-    add(0, Z_D0, 128, 0, 128, S_FEAT, 256, 128, 128, G_D0A + 128, 256, -1);
-    add(0, Z_D0, 128, 0, 128, S_DIRF, 16, 0, 16, G_D0B, 16, -1);
-    add(0, Z_D1, 128, 0, 128, S_D0, 128, 0, 128, G_D1, 128, CS_D0 + 128);
-    add(0, Z_D2, 128, 0, 128, S_D1, 128, 0, 128, G_D2, 128, CS_D0 + 256);
-    add(1, 0, 4, 0, 4, S_D2, 128, 0, 128, G_RGB, 128, CS_RGB);             // rows 0..2: fc_rgb.weight; cs[3] = d b_alpha
-    add(1, 0, 4, 0, 4, S_FEAT, 256, 0, 128, G_ALPHA, 256, -1);             // row 3 (d sigma): fc_alpha.weight
-    add(1, 0, 4, 0, 4, S_FEAT, 256, 128, 128, G_ALPHA + 128, 256, -1);
-    // n == NF_DW_JOBS by construction
-}
-
-// The same 36 products as groups of four that share operand panels (k_dw_gemm_lds, nf_mlp_dw.h)
+// The 36 products (128 x 128 each) as groups of four that share operand panels (k_dw_gemm_lds, nf_mlp_dw.h)
 #define NF_DW_GROUPS 9
 
 static void nf_build_dw_groups(NfDwGroup* gr) {
@@ -414,9 +312,7 @@ int nfb_launch_dw_gemm_f16(int model, const float* dz, const float* d_raw, const
 
 extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
-    nf_bwd_plan(n_points, &pps, &ns);
-    nfb_dw_plan(0, n_points, &pps, &ns_b);
-    if (ns_b > ns) ns = ns_b;
+    nfb_dw_plan(0, n_points, &pps, &ns);
     NfDwGroup groups[NF_DW_GROUPS];
     nf_build_dw_groups(groups);
     ns_b = nf_dw_plan_groups(groups, NF_DW_GROUPS, n_points);
@@ -424,7 +320,6 @@ extern "C" size_t nf_paper_bwd_workspace_floats(int64_t n_points) {
     return (size_t)nfl::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nfl::SLAB_FLOATS + 16;      // + max |gradient| per dz section (fp16 kernels)
 }
 
-static NfDwJobTable g_paper_jobs;
 
 // defined in nf_mlp_bf16_bwd.hip / nf_mlp_f16_bwd.hip
 int nfb_launch_bwd_chain_bf16(const void* packed_t, const float* saved, const float* d_raw, int64_t n_points, float* dz,
@@ -448,13 +343,9 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;
     if (dev < 0 || dev >= 64) return NF_EINVAL;
-    const NfDwJob* jobs = nullptr;
-    const int rcj = g_paper_jobs.get(NF_DW_JOBS, nf_build_dw_jobs, &jobs);
-    if (rcj) return rcj;
     int64_t pps; int ns;
     NfDwGroupSet gset;
     if (split_dw) nfb_dw_plan(0, n_points, &pps, &ns);
-    else if (nf_legacy_train()) nf_bwd_plan(n_points, &pps, &ns);
     else {
         nf_build_dw_groups(gset.g);
         for (int k = 0; k <= NF_DW_MAX_GROUPS; ++k) gset.first_block[k] = 0x7fffffff;
@@ -475,8 +366,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     for (int q = 0; q < NF_REDUCE_ALT_MAX; ++q) alt.lo4[q] = alt.hi4[q] = 0;
     // the slabs are fully written by the GEMM kernel -- except, in the shared-panel plan, by the group that runs fewer slices: the
     // reduction is told which regions end early instead of a 71 MB zero-fill per call
-    const bool lds_plan = !split_dw && !nf_legacy_train();
-    if (!(lds_plan && nf_dw_reduce_alt(gset.g, NF_DW_GROUPS, ns, &alt))) {
+    if (!(!split_dw && nf_dw_reduce_alt(gset.g, NF_DW_GROUPS, ns, &alt))) {
         alt.n_slices = 0;
         e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
         if (e != hipSuccess) return (int)e;
@@ -497,12 +387,8 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
         if (rc2) return rc2;
     } else {
         mark(0);
-        if (nf_legacy_train())
-            hipLaunchKernelGGL((k_paper_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
-                               n_points, dz);
-        else
-            hipLaunchKernelGGL((k_paper_mlp_bwd_chain_masks<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved,
-                               d_raw, n_points, dz);
+        hipLaunchKernelGGL((k_paper_mlp_bwd_chain_masks<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw,
+                           n_points, dz);
     }
     mark(1);
     if (split_dw) {
@@ -510,13 +396,8 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
                                      : nfb_launch_dw_gemm_bf16(0, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc3) return rc3;
     } else {
-        if (nf_legacy_train()) {
-            hipLaunchKernelGGL((k_dw_gemm<0>), dim3((NF_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_DW_JOBS, (int)SLAB_FLOATS, dz, d_raw,
-                               saved, n_points, pps, slabs);
-        } else {
-            hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(gset.first_block[NF_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz, d_raw, saved,
-                               n_points, slabs);
-        }
+        hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(gset.first_block[NF_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz, d_raw, saved,
+                           n_points, slabs);
     }
     mark(2);
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, alt);
@@ -579,15 +460,21 @@ extern "C" int nf_paper_mlp_bwd_f16(const float* packed, const void* packed_t_f1
                        grads, stream);
 }
 
-// host-only self-test of the exact-f32 job table (tests/test_host.py)
+// host-only self-test of the exact-f32 group table (tests/test_host.py)
 extern "C" int nf_selftest_dw_tables_f32(void) {
-    NfDwJob jobs[NF_DW_JOBS];
-    nf_build_dw_jobs(jobs);
     const long paper = 2L * 256 * 64 + 6L * 65536 + 128L * 272 + 2L * 128 * 128 + 4L * 128 + 4L * 256 + 7 * 256 + 3 * 128 + 4;
-    const int rc = nf_check_dw_jobs(jobs, NF_DW_JOBS, nfl::SLAB_FLOATS, paper);
-    if (rc) return rc;
     NfDwGroup groups[NF_DW_GROUPS];
     nf_build_dw_groups(groups);
-    const int rg = nf_check_dw_groups(groups, NF_DW_GROUPS, nfl::SLAB_FLOATS, paper);
-    return rg ? rg - 100 : 0;
+    int rc = nf_check_dw_groups(groups, NF_DW_GROUPS, nfl::SLAB_FLOATS, paper);
+    if (rc) return rc;
+    // the plan at the training sizes: one workgroup per CU at most, and the reduction can describe the short groups
+    for (int64_t n : {(int64_t)131072, (int64_t)262144, (int64_t)259969, (int64_t)512}) {
+        int first[NF_DW_MAX_GROUPS + 1];
+        const int most = nf_dw_plan_groups(groups, NF_DW_GROUPS, n, first);
+        NfReduceAlt alt;
+        if (first[NF_DW_GROUPS] > 256 || most < 1 || !nf_dw_reduce_alt(groups, NF_DW_GROUPS, most, &alt)) return -200;
+        for (int i = 0; i < NF_DW_GROUPS; ++i)
+            if ((int64_t)groups[i].n_slices * groups[i].pts_per_slice < n || (groups[i].pts_per_slice & 15)) return -201;
+    }
+    return 0;
 }

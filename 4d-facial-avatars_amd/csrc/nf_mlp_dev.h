@@ -291,10 +291,8 @@ struct NfCopySide {
         for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, k, lane);
     }
     __device__ __forceinline__ void half1(int it) const {
-#ifndef NF_ABL_NOCOPY
 #pragma unroll
         for (int k = 0; k < PER; ++k) nf_copy_write<W4>(cv[k], cp, it * PER + k, lane);
-#endif
     }
     __device__ __forceinline__ void half2(int it) {                      // past the last iteration: re-read its rows (unused)
         const int nx = it + 1 < n_it ? it + 1 : it;

@@ -788,7 +788,7 @@ def main():
         ms = {"f32": timed(lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
               "bf16x3": timed(lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z)),
               "f16x3": timed(lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z))}
-        objs = {"f32": {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2,false> (65536 rays x 192 samples per launch)",
+        objs = {"f32": {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2> (65536 rays x 192 samples per launch)",
                         "achieved": flops / (ms["f32"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": flops / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms["f32"],
                         "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes, "traffic": None,
