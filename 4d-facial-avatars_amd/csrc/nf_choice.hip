@@ -19,7 +19,8 @@
 #include "nf_common.h"
 
 #define NF_CHOICE_BINS 4096
-#define NF_CHOICE_MAX_BLOCKS 64
+#define NF_CHOICE_MAX_BLOCKS 64        // level passes (global histogram atomics: few workgroups)
+#define NF_CHOICE_MAX_CBLOCKS 1024     // compaction passes (no atomics: one 256-item tile per workgroup on a 512 x 512 frame)
 struct NfChoiceState {            // workspace header (uint32 words): zeroed by the host-side memset before the first level
     unsigned done;                // workgroups that have flushed their histogram (reset by the scanning workgroup)
     unsigned prefix;              // key bits fixed so far
@@ -204,7 +205,7 @@ __global__ void __launch_bounds__(256) k_choice_emit(const float* __restrict__ w
 }
 
 extern "C" size_t nf_weighted_choice_workspace_bytes(void) {
-    return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned) + 2 * NF_CHOICE_MAX_BLOCKS * sizeof(unsigned);
+    return sizeof(NfChoiceState) + NF_CHOICE_BINS * sizeof(unsigned) + 2 * NF_CHOICE_MAX_CBLOCKS * sizeof(unsigned);
 }
 
 extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t n_items, int n_select, int64_t* idx_out, void* workspace,
@@ -226,7 +227,8 @@ extern "C" int nf_weighted_choice(const float* weights, const float* u, int64_t 
     hipLaunchKernelGGL(k_choice_level<0>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<1>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
     hipLaunchKernelGGL(k_choice_level<2>, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, hist);
-    hipLaunchKernelGGL(k_choice_count, dim3(grid), dim3(256), 0, s, weights, u, n_items, st, counts);
-    hipLaunchKernelGGL(k_choice_emit, dim3(grid), dim3(256), 0, s, weights, u, n_items, n_select, st, counts, idx_out);
+    const int cgrid = (int)(want < NF_CHOICE_MAX_CBLOCKS ? want : NF_CHOICE_MAX_CBLOCKS);
+    hipLaunchKernelGGL(k_choice_count, dim3(cgrid), dim3(256), 0, s, weights, u, n_items, st, counts);
+    hipLaunchKernelGGL(k_choice_emit, dim3(cgrid), dim3(256), 0, s, weights, u, n_items, n_select, st, counts, idx_out);
     NF_RETURN_LAUNCH();
 }

@@ -227,7 +227,9 @@ static void nf_build_dw_groups(NfDwGroup* gr) {
 // =================================================================================================
 // B3: reduce over slices + scatter to the reference parameter layout
 // =================================================================================================
-struct NfGradOffsets { int off[NF_PAPER_NUM_PARAMS + 1]; };
+// off[t]: first flat element of tensor t; blk[t]: first workgroup of tensor t (a workgroup handles 256 elements of ONE tensor, so
+// the tensor id -- and with it the switch below -- is uniform: no per-element search, no divergence); tensor 26 = d latent
+struct NfGradOffsets { int off[NF_PAPER_NUM_PARAMS + 2]; int blk[NF_PAPER_NUM_PARAMS + 2]; };
 
 __device__ __forceinline__ int nf_pe_col_to_slot(int col) { return nfl::pe_col_to_slot(col); }
 
@@ -237,19 +239,22 @@ __global__ void __launch_bounds__(256) k_paper_grad_unpack(const float* __restri
     using namespace nfl;
     const float* cvec = cond + B_CVEC;
     const float* dvec = cond + B_DVEC;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < GRAD_FLOATS; e += gridDim.x * blockDim.x) {
+    int t = 0;
+    while ((int)blockIdx.x >= offs.blk[t + 1]) ++t;                 // uniform
+    const int local = ((int)blockIdx.x - offs.blk[t]) * 256 + (int)threadIdx.x;
+    if (local >= offs.off[t + 1] - offs.off[t]) return;
+    const int e = offs.off[t] + local;
+    {
         float v = 0.f;
-        if (e >= GRAD_PARAM_FLOATS) {                                // d latent_j = sum_n W0[n][139+j] db0[n] + W3[n][139+j] db3[n]
-            const int j = e - GRAD_PARAM_FLOATS;
+        if (t == NF_PAPER_NUM_PARAMS) {                              // d latent_j = sum_n W0[n][139+j] db0[n] + W3[n][139+j] db3[n]
+            const int j = local;
             const float* w0 = packed + OFF_WC0 + 76 + j;
             const float* w3 = packed + OFF_WC3 + 76 + j;
             for (int n = 0; n < 256; ++n) v += w0[n * NCOND] * sum[CS_L0 + n] + w3[n * NCOND] * sum[CS_L0 + 768 + n];
             grads[e] = v;
-            continue;
+            return;
         }
-        int t = 0;
-        while (e >= offs.off[t + 1]) ++t;
-        const int local = e - offs.off[t];
+
         switch (t) {
             case 0: {  // layers_xyz.0.weight [256][171]
                 const int n = local / 171, col = local - 171 * n;
@@ -402,9 +407,13 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     mark(2);
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, alt);
     NfGradOffsets offs;
-    offs.off[0] = 0;
-    for (int i = 0; i < NF_PAPER_NUM_PARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_PARAM_NUMEL[i];
-    hipLaunchKernelGGL(k_paper_grad_unpack, dim3((GRAD_FLOATS + 255) / 256), dim3(256), 0, s, sum, packed, cond, offs, grads);   // one element per thread: the kernel is a dependent search + gather, i.e. latency
+    offs.off[0] = offs.blk[0] = 0;
+    for (int i = 0; i <= NF_PAPER_NUM_PARAMS; ++i) {                  // 26 tensors, then the 32 latent-code gradients
+        const int numel = i < NF_PAPER_NUM_PARAMS ? NF_PARAM_NUMEL[i] : 32;
+        offs.off[i + 1] = offs.off[i] + numel;
+        offs.blk[i + 1] = offs.blk[i] + (numel + 255) / 256;
+    }
+    hipLaunchKernelGGL(k_paper_grad_unpack, dim3(offs.blk[NF_PAPER_NUM_PARAMS + 1]), dim3(256), 0, s, sum, packed, cond, offs, grads);
     if (stage_ms) {
         mark(3);
         e = hipStreamSynchronize(s);

@@ -309,13 +309,14 @@ __device__ __forceinline__ void nf_mma_from_lds_copy(f32x4 (&acc)[NT][16], const
     nf_mma_from_lds_side<NT, NO>(acc, wsec, nch, act4, lane, side);
 }
 
-// ReLU bit masks of the exact-f32 kernels: section nfl::S_MASK of `saved`, [9 layers][ceil(n / 16) point tiles][64 lanes][2 dwords];
+// ReLU bit masks of the exact-f32 kernels: section S_MASK of `saved`, [ReLU layers: 9 paper / 5 second family][ceil(n / 16) point tiles][64 lanes][2 dwords];
 // bit 4 no + r of lane (g, c) <-> feature 16 no + 4 g + r of point 16 tile + c (the D-register order of the f32 MFMA tiles), i.e.
 // exactly what the lane holds: one 8-byte store per lane and tile in the forward, one 8-byte load in the backward chain.
 // (The split-bf16/fp16 kernels keep their own bit order in the same section; a `saved` buffer goes back to the family that wrote it.)
+template <int S_MASK_SEC = nfl::S_MASK>       // section offset of the model family's mask words (floats per point)
 __device__ __forceinline__ uint2* nf_mask_ptr(float* saved, int64_t n, int layer, int64_t tile, int lane) {
     const int64_t n_tiles = (n + 15) >> 4;
-    return reinterpret_cast<uint2*>(saved + (int64_t)nfl::S_MASK * n) + ((int64_t)layer * n_tiles + tile) * 64 + lane;
+    return reinterpret_cast<uint2*>(saved + (int64_t)S_MASK_SEC * n) + ((int64_t)layer * n_tiles + tile) * 64 + lane;
 }
 
 // acc = max(acc, 0); returns the mask bits of the lane ([x > 0], exact also for +-0: the int view of a float is > 0 iff the float is)

@@ -105,12 +105,11 @@ extern "C" int nf_lcode_condition(const float* packed, const float* expr76, cons
     NF_RETURN_LAUNCH();
 }
 
-// SAVE = training forward: every layer output is also written to `saved` (layout nlc::S_*).
-template <int NT, bool SAVE>
+template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z, int64_t n_points, int S,
-                float* __restrict__ raw, float* __restrict__ saved) {
+                float* __restrict__ raw) {
     using namespace nlc;
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -134,18 +133,12 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
-        if (SAVE && p0 + 16 * t + c < n_points) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(saved + S_PE * n_points + p * 64 + 16 * j + 4 * g) = pe[t][j];
-            *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
-        }
     }
     f32x4 acc[NT][16];
 #define NF_LC_FINISH(NO_, RELU_, SEC_, WIDTH_)                                                        \
     do {                                                                                              \
         if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                     \
         nf_store_act<NT, NO_, false>(acc, act4, lane);                                                \
-        if (SAVE) nf_store_global<NT, NO_>(acc, saved + (int64_t)(SEC_) * n_points, WIDTH_, p0, n_points, lane); \
     } while (0)
     nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
     nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
@@ -183,6 +176,96 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
 }
 
+// Training forward (exact f32): the same arithmetic plus `saved` (layout nlc::S_*) -- every layer output as whole rows out of the
+// wave's LDS slab from inside the next layer's K loop, ReLU bit masks beside them (nf_mlp_dev.h; the paper model's
+// k_paper_mlp_fwd_save is the template).  layers_xyz.2's output is read by fc_alpha AND fc_feat: it is copied under fc_feat's loop.
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_lcode_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
+                     const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z, int64_t n_points, int S,
+                     float* __restrict__ raw, float* __restrict__ saved) {
+    using namespace nlc;
+    static_assert(NT == 2, "the copy schedule below is written for 32-point slabs");
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
+    const int64_t n = n_points;
+    auto sec = [&](int s_, int width) { return nf_slab_copy(saved, s_, width, p0, n); };
+    f32x4 pe[NT][4];
+    f32x4 dirf[NT][1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const int64_t ray = p / S;
+        const float zz = z[p];
+        const float px = nf_add(ro[ray * 3 + 0], nf_mul(rd[ray * 3 + 0], zz));
+        const float py = nf_add(ro[ray * 3 + 1], nf_mul(rd[ray * 3 + 1], zz));
+        const float pz = nf_add(ro[ray * 3 + 2], nf_mul(rd[ray * 3 + 2], zz));
+        nf_encode_point(px, py, pz, g, pe[t]);
+        float s, cs;
+        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
+        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+        if (p0 + 16 * t + c < n_points) *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) act4[nf_act_idx4(16 * t + c, 4 * j + g)] = pe[t][j];
+    }
+    {
+        const NfSlabCopy cp = sec(S_PE, 64);
+#pragma unroll
+        for (int k = 0; k < 16 * NT / 4; ++k) nf_copy_rows<16>(act4, cp, k, lane);
+    }
+    f32x4 acc[NT][16];
+    uint2 m[NT];
+#define NF_LC_FINISH_SAVE(NO_, MASKL_)                                                                   \
+    do {                                                                                                \
+        if ((MASKL_) >= 0) {                                                                            \
+            nf_relu_with_mask<NT, NO_>(acc, m);                                                         \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                              \
+                if (p0 + 16 * t < n) *nf_mask_ptr<S_MASK>(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t]; \
+        }                                                                                               \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
+    } while (0)
+    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
+    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
+    NF_LC_FINISH_SAVE(16, -1);
+    nf_init_acc<NT, 16>(acc, cond + B_X0, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X0 / 4, 16, act4, lane, sec(S_L1, 256));
+    NF_LC_FINISH_SAVE(16, 0);
+    nf_init_acc<NT, 16>(acc, cond + B_X1, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X1 / 4, 16, act4, lane, sec(S_X0, 256));
+    NF_LC_FINISH_SAVE(16, 1);
+    nf_init_acc<NT, 16>(acc, cond + B_X2, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X2 / 4, 16, act4, lane, sec(S_X1, 256));
+    NF_LC_FINISH_SAVE(16, 2);
+    nf_init_acc<NT, 1>(acc, cond + B_ALPHA, lane);                       // fc_alpha(x)
+    nf_mma_from_lds<NT, 1>(acc, W + OFF_ALPHA / 4, 16, act4, lane);
+    float sigma_raw[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
+    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);                       // feat = relu(fc_feat(x))
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_FEAT / 4, 16, act4, lane, sec(S_X2, 256));
+    NF_LC_FINISH_SAVE(16, 3);
+    nf_init_acc<NT, 8>(acc, cond + B_DIR, lane);                         // relu(layers_dir.0([feat | dir]))
+    nf_mma_from_lds_copy<NT, 8, 64, 4>(acc, W + OFF_DIR / 4, 16, act4, lane, sec(S_FEAT, 256));
+    nf_mma_from_regs<NT, 8, 1>(acc, W + OFF_DIR / 4 + 16 * 8 * 64, dirf, lane);
+    NF_LC_FINISH_SAVE(8, 4);
+#undef NF_LC_FINISH_SAVE
+    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
+    nf_mma_from_lds_copy<NT, 1, 32, 4>(acc, W + OFF_RGB / 4, 8, act4, lane, sec(S_DIR, 128));
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t p = p0 + 16 * t + c;
+            if (p < n_points) reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+        }
+    }
+}
+
 static int nf_lcode_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
@@ -193,12 +276,13 @@ static int nf_lcode_launch_fwd(const float* packed, const float* cond, const flo
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    if (saved && n_points >= ((int64_t)1 << 22)) return NF_EINVAL;       // the save path addresses a section with 32-bit byte offsets (1 KiB per point)
     if (saved)
-        hipLaunchKernelGGL((k_lcode_mlp_fwd<NT, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
+        hipLaunchKernelGGL((k_lcode_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
                            rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
-        hipLaunchKernelGGL((k_lcode_mlp_fwd<NT, false>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
-                           rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, (float*)nullptr);
+        hipLaunchKernelGGL((k_lcode_mlp_fwd<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, ro,
+                           rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
     NF_RETURN_LAUNCH();
 }
 
@@ -207,7 +291,8 @@ extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const fl
     return nf_lcode_launch_fwd(packed, cond, ro, rd, rd_view, z, n_rays, n_samples, raw, nullptr, stream);
 }
 
-extern "C" size_t nf_lcode_saved_floats(int64_t n_points) { return (size_t)nlc::SAVED_PER_POINT * (size_t)n_points; }
+// + one point tile of mask words (the exact-f32 masks are kept per 16-point tile)
+extern "C" size_t nf_lcode_saved_floats(int64_t n_points) { return (size_t)nlc::SAVED_PER_POINT * (size_t)n_points + 5 * 128; }
 
 // Training forward: also fills `saved` (nf_lcode_saved_floats(n_points) floats), which nf_lcode_mlp_bwd reads.
 extern "C" int nf_lcode_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,

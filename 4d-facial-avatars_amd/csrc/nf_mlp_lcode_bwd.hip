@@ -58,30 +58,14 @@ __device__ __forceinline__ void nf_lc_zero_acc(f32x4 (&acc)[NT][16]) {
         for (int t = 0; t < NT; ++t) acc[t][no] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// acc *= [X > 0] with X read from the saved activations ([n_points][width] row-major)
-template <int NT, int NO>
-__device__ __forceinline__ void nf_lc_mask(f32x4 (&acc)[NT][16], const float* __restrict__ sec, int width, int64_t p0, int64_t n_points,
-                                           int lane) {
-    const int g = lane >> 4, c = lane & 15;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        int64_t p = p0 + 16 * t + c;
-        if (p >= n_points) p = n_points - 1;
-#pragma unroll
-        for (int no = 0; no < NO; ++no) {
-            const f32x4 x = *reinterpret_cast<const f32x4*>(sec + p * width + 16 * no + 4 * g);
-            f32x4 v = acc[t][no];
-            v.x = x.x > 0.f ? v.x : 0.f; v.y = x.y > 0.f ? v.y : 0.f; v.z = x.z > 0.f ? v.z : 0.f; v.w = x.w > 0.f ? v.w : 0.f;
-            acc[t][no] = v;
-        }
-    }
-}
-
+// ReLU masks from the bit masks the training forward left in section S_MASK (five layers, fetched at kernel entry); every dZ section
+// leaves through the wave's LDS slab as whole rows from inside the next layer's K loop (nf_mlp_dev.h; cf. k_paper_mlp_bwd_chain_masks).
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
                       int64_t n_points, float* __restrict__ dz) {
     using namespace nlc;
+    static_assert(NT == 2, "the copy schedule below is written for 32-point slabs");
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
@@ -90,7 +74,14 @@ k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restric
     f32x4* act4 = lds + wave * (16 * NT * 64);
     const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
     const int64_t n = n_points;
+    auto sec = [&](int zs, int width) { return nf_slab_copy(dz, zs, width, p0, n); };
 
+    uint2 m[5][NT];                                   // layers_xyz.0..2, fc_feat, layers_dir.0
+#pragma unroll
+    for (int l = 0; l < 5; ++l)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            m[l][t] = p0 + 16 * t < n ? *nf_mask_ptr<S_MASK>(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
     f32x4 frag_rgb[NT][1], frag_sig[NT][1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -101,65 +92,102 @@ k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restric
         frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
     }
     f32x4 acc[NT][16];
-#define NF_LC_BWD_FINISH(NO_, MASKSEC_, MASKW_, ZSEC_)                                                  \
-    do {                                                                                                \
-        if ((MASKSEC_) >= 0) nf_lc_mask<NT, NO_>(acc, saved + (int64_t)(MASKSEC_) * n, MASKW_, p0, n, lane); \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
-        nf_store_global<NT, NO_>(acc, dz + (int64_t)(ZSEC_) * n, (NO_) * 16, p0, n, lane);              \
+#define NF_LC_BWD_FINISH(NO_, MASKL_)                                                 \
+    do {                                                                              \
+        if ((MASKL_) >= 0) nf_apply_mask<NT, NO_>(acc, m[(MASKL_) < 0 ? 0 : (MASKL_)]); \
+        nf_store_act<NT, NO_, false>(acc, act4, lane);                                \
     } while (0)
     // d(layers_dir.0 out) = d rgb . fc_rgb.weight, masked by its ReLU
     nf_lc_zero_acc<NT, 8>(acc);
     nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
-    NF_LC_BWD_FINISH(8, S_DIR, 128, Z_DIR);
+    NF_LC_BWD_FINISH(8, 4);
     // d feat = dZ_dir . layers_dir.0.weight[:, :256], masked by relu(fc_feat)
     nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_DIR / 4, 8, act4, lane);
-    NF_LC_BWD_FINISH(16, S_FEAT, 256, Z_FEAT);
+    nf_mma_from_lds_copy<NT, 16, 32, 4>(acc, WT + OFFT_DIR / 4, 8, act4, lane, sec(Z_DIR, 128));
+    NF_LC_BWD_FINISH(16, 3);
     // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight, masked by layers_xyz.2's ReLU
     nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_FEAT / 4, 16, act4, lane);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_FEAT / 4, 16, act4, lane, sec(Z_FEAT, 256));
     nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_FEAT / 4 + 16 * 16 * 64, frag_sig, lane);
-    NF_LC_BWD_FINISH(16, S_X2, 256, Z_X2);
+    NF_LC_BWD_FINISH(16, 2);
     nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X2 / 4, 16, act4, lane);
-    NF_LC_BWD_FINISH(16, S_X1, 256, Z_X1);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X2 / 4, 16, act4, lane, sec(Z_X2, 256));
+    NF_LC_BWD_FINISH(16, 1);
     nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X1 / 4, 16, act4, lane);
-    NF_LC_BWD_FINISH(16, S_X0, 256, Z_X0);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X1 / 4, 16, act4, lane, sec(Z_X1, 256));
+    NF_LC_BWD_FINISH(16, 0);
     // d(layer1 out): layer1 has no activation (M:609)
     nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds<NT, 16>(acc, WT + OFFT_X0 / 4, 16, act4, lane);
-    NF_LC_BWD_FINISH(16, -1, 256, Z_L1);
+    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X0 / 4, 16, act4, lane, sec(Z_X0, 256));
+    NF_LC_BWD_FINISH(16, -1);
 #undef NF_LC_BWD_FINISH
+    {   // the last section has no K loop behind it
+        const NfSlabCopy cp = sec(Z_L1, 256);
+#pragma unroll 4
+        for (int k = 0; k < 16 * NT; ++k) nf_copy_rows<64>(act4, cp, k, lane);
+    }
 }
 
 // =================================================================================================
 // B2 job table
 // =================================================================================================
-#define NF_LC_DW_JOBS 24
-static void nf_lcode_build_dw_jobs(NfDwJob* j) {
+// the 24 products (128 x 128 each) as groups of four that share operand panels (k_dw_gemm_lds, nf_mlp_dw.h)
+#define NF_LC_DW_GROUPS 6
+static void nf_lcode_build_dw_groups(NfDwGroup* gr) {
     using namespace nlc;
     int n = 0;
-    auto add = [&](int a_kind, int a_sec, int lda, int a_col0, int n_valid, int b_sec, int ldb, int b_col0, int k_valid, int out_off,
-                   int ldo, int cs_off) { j[n++] = NfDwJob{a_kind, a_sec, lda, a_col0, n_valid, b_sec, ldb, b_col0, k_valid, out_off, ldo, cs_off}; };
-    auto layer256 = [&](int zsec, int bsec, int ldb, int kdim, int gout, int cs) {
-        for (int nb = 0; nb < 2; ++nb)
-            for (int kb = 0; kb * 128 < kdim; ++kb)
-                add(0, zsec, 256, 128 * nb, 128, bsec, ldb, 128 * kb, kdim - 128 * kb < 128 ? kdim - 128 * kb : 128,
-                    gout + 128 * nb * kdim + 128 * kb, kdim, kb == 0 ? cs + 128 * nb : -1);
+    const NfDwPanel off{-1, 0, 0, 0, 0};
+    auto fresh = [&]() -> NfDwGroup& {
+        NfDwGroup& g = gr[n++];
+        for (auto& p : g.panel) p = off;
+        g.share = 2;
+        g.n_slices = g.pts_per_slice = 0;
+        return g;
     };
-    layer256(Z_L1, S_PE, 64, 64, G_L1, CS_L1);
-    layer256(Z_X0, S_L1, 256, 256, G_X0, CS_L1 + 256);
-    layer256(Z_X1, S_X0, 256, 256, G_X1, CS_L1 + 512);
-    layer256(Z_X2, S_X1, 256, 256, G_X2, CS_L1 + 768);
-    layer256(Z_FEAT, S_X2, 256, 256, G_FEAT, CS_L1 + 1024);
-    add(0, Z_DIR, 128, 0, 128, S_FEAT, 256, 0, 128, G_DIRA, 256, CS_DIR);
-    add(0, Z_DIR, 128, 0, 128, S_FEAT, 256, 128, 128, G_DIRA + 128, 256, -1);
-    add(0, Z_DIR, 128, 0, 128, S_DIRF, 16, 0, 16, G_DIRB, 16, -1);
-    add(1, 0, 4, 0, 4, S_DIR, 128, 0, 128, G_RGB, 128, CS_RGB);            // rows 0..2: fc_rgb.weight; cs[3] = d b_alpha
-    add(1, 0, 4, 0, 4, S_X2, 256, 0, 128, G_ALPHA, 256, -1);               // row 3 (d sigma): fc_alpha.weight (fc_alpha reads x)
-    add(1, 0, 4, 0, 4, S_X2, 256, 128, 128, G_ALPHA + 128, 256, -1);
-    // n == NF_LC_DW_JOBS by construction
+    auto job = [](const NfDwGroup& g, int a, int b, int out_off, int ldo, int cs) {
+        return NfDwWaveJob{a, b, g.panel[a].valid, g.panel[b].valid, out_off, ldo, cs};
+    };
+    auto layer256 = [&](int zsec, int bsec, int gout, int cs) {
+        NfDwGroup& g = fresh();
+        for (int h = 0; h < 2; ++h) {
+            g.panel[h] = NfDwPanel{0, zsec, 256, 128 * h, 128};
+            g.panel[2 + h] = NfDwPanel{2, bsec, 256, 128 * h, 128};
+        }
+        for (int nb = 0; nb < 2; ++nb)
+            for (int kb = 0; kb < 2; ++kb)
+                g.wave[2 * nb + kb] = job(g, nb, 2 + kb, gout + 128 * nb * 256 + 128 * kb, 256, kb == 0 ? cs + 128 * nb : -1);
+    };
+    layer256(Z_X0, S_L1, G_X0, CS_L1 + 256);
+    layer256(Z_X1, S_X0, G_X1, CS_L1 + 512);
+    layer256(Z_X2, S_X1, G_X2, CS_L1 + 768);
+    layer256(Z_FEAT, S_X2, G_FEAT, CS_L1 + 1024);
+    {   // dZ_L1 x PE (two row blocks), dZ_dir x (dir slots | feat columns 0..127)
+        NfDwGroup& g = fresh();
+        g.panel[0] = NfDwPanel{0, Z_L1, 256, 0, 128};
+        g.panel[1] = NfDwPanel{0, Z_L1, 256, 128, 128};
+        g.panel[2] = NfDwPanel{2, S_PE, 64, 0, 64};
+        g.panel[3] = NfDwPanel{0, Z_DIR, 128, 0, 128};
+        g.panel[4] = NfDwPanel{2, S_DIRF, 16, 0, 16};
+        g.panel[5] = NfDwPanel{2, S_FEAT, 256, 0, 128};
+        g.wave[0] = job(g, 0, 2, G_L1, 64, CS_L1);
+        g.wave[1] = job(g, 1, 2, G_L1 + 128 * 64, 64, CS_L1 + 128);
+        g.wave[2] = job(g, 3, 4, G_DIRB, 16, -1);
+        g.wave[3] = job(g, 3, 5, G_DIRA, 256, CS_DIR);
+    }
+    {   // dZ_dir x feat columns 128..255; d_raw x (dir-layer output | x2): rows 0..2 = fc_rgb.weight, row 3 (d sigma) = fc_alpha.weight
+        NfDwGroup& g = fresh();
+        g.panel[0] = NfDwPanel{0, Z_DIR, 128, 0, 128};
+        g.panel[1] = NfDwPanel{2, S_FEAT, 256, 128, 128};
+        g.panel[2] = NfDwPanel{1, 0, 4, 0, 4};
+        g.panel[3] = NfDwPanel{2, S_DIR, 128, 0, 128};
+        g.panel[4] = NfDwPanel{2, S_X2, 256, 0, 128};
+        g.panel[5] = NfDwPanel{2, S_X2, 256, 128, 128};
+        g.wave[0] = job(g, 0, 1, G_DIRA + 128, 256, -1);
+        g.wave[1] = job(g, 2, 3, G_RGB, 128, CS_RGB);
+        g.wave[2] = job(g, 2, 4, G_ALPHA, 256, -1);
+        g.wave[3] = job(g, 2, 5, G_ALPHA + 128, 256, -1);
+    }
+    // n == NF_LC_DW_GROUPS by construction
 }
 
 // =================================================================================================
@@ -235,13 +263,14 @@ int nfb_lcode_launch_bwd_chain_f16(const void* packed_t, const float* saved, con
 
 extern "C" size_t nf_lcode_bwd_workspace_floats(int64_t n_points) {
     int64_t pps; int ns, ns_b;
-    nf_bwd_plan(n_points, &pps, &ns);
-    nfb_dw_plan(1, n_points, &pps, &ns_b);
+    nfb_dw_plan(1, n_points, &pps, &ns);
+    NfDwGroup groups[NF_LC_DW_GROUPS];
+    nf_lcode_build_dw_groups(groups);
+    ns_b = nf_dw_plan_groups(groups, NF_LC_DW_GROUPS, n_points);
     if (ns_b > ns) ns = ns_b;
     return (size_t)nlc::DZ_PER_POINT * (size_t)n_points + (size_t)(ns + 1) * nlc::SLAB_FLOATS + 16;      // + max |gradient| per dz section (fp16 kernels)
 }
 
-static NfDwJobTable g_lcode_jobs;
 
 // grads: nf_lcode_grad_floats() floats = the 16 tensors in nerf.models.LCODE_KEYS order, flattened, then d latent (32)
 // packed_t (exact f32) | packed_t_bf16 (split-bf16) | packed_t_f16 (split-fp16): exactly one non-NULL
@@ -255,12 +284,22 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     const bool split = packed_t_bf16 != nullptr || packed_t_f16 != nullptr;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_lcode_bwd_workspace_floats(n_points)) return NF_EINVAL;
-    const NfDwJob* jobs = nullptr;
-    const int rcj = g_lcode_jobs.get(NF_LC_DW_JOBS, nf_lcode_build_dw_jobs, &jobs);
-    if (rcj) return rcj;
+    if (n_points >= ((int64_t)1 << 22)) return NF_EINVAL;                // 32-bit byte offsets into a dZ section (exact-f32 chain)
     int64_t pps; int ns;
+    NfDwGroupSet gset;
+    NfReduceAlt alt;
+    alt.n_slices = 0;
+    for (int q = 0; q < NF_REDUCE_ALT_MAX; ++q) alt.lo4[q] = alt.hi4[q] = 0;
+    bool zero_fill = true;
     if (split) nfb_dw_plan(1, n_points, &pps, &ns);
-    else nf_bwd_plan(n_points, &pps, &ns);
+    else {
+        nf_lcode_build_dw_groups(gset.g);
+        for (int k = 0; k <= NF_DW_MAX_GROUPS; ++k) gset.first_block[k] = 0x7fffffff;
+        ns = nf_dw_plan_groups(gset.g, NF_LC_DW_GROUPS, n_points, gset.first_block);
+        pps = 0;
+        zero_fill = !nf_dw_reduce_alt(gset.g, NF_LC_DW_GROUPS, ns, &alt);   // every group writes every slab: nothing to clear
+        if (zero_fill) alt.n_slices = 0;
+    }
     float* dz = workspace;
     float* slabs = workspace + (size_t)DZ_PER_POINT * n_points;
     float* sum = slabs + (size_t)ns * SLAB_FLOATS;
@@ -270,8 +309,11 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
-    hipError_t e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
-    if (e != hipSuccess) return (int)e;
+    hipError_t e = hipSuccess;
+    if (zero_fill) {
+        e = hipMemsetAsync(slabs, 0, (size_t)ns * SLAB_FLOATS * sizeof(float), s);
+        if (e != hipSuccess) return (int)e;
+    }
     if (packed_t_f16) {
         e = hipMemsetAsync(gscale, 0, 16 * sizeof(float), s);           // max |gradient| per section, filled by the chain
         if (e != hipSuccess) return (int)e;
@@ -286,10 +328,10 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
         if (rc) return rc;
     } else {
         hipLaunchKernelGGL((k_lcode_mlp_bwd_chain<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, s, packed_t, saved, d_raw, n_points, dz);
-        hipLaunchKernelGGL((k_dw_gemm<1>), dim3((NF_LC_DW_JOBS + 3) / 4, ns), dim3(256), 0, s, jobs, NF_LC_DW_JOBS, (int)SLAB_FLOATS, dz,
-                           d_raw, saved, n_points, pps, slabs);
+        hipLaunchKernelGGL((k_dw_gemm_lds<1>), dim3(gset.first_block[NF_LC_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz,
+                           d_raw, saved, n_points, slabs);
     }
-    hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, NfReduceAlt{});
+    hipLaunchKernelGGL((k_grad_reduce<1>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, alt);
     NfLcodeGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NPARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_LC_PARAM_NUMEL[i];
@@ -324,10 +366,18 @@ extern "C" int nf_lcode_mlp_bwd_f16(const float* packed, const void* packed_t_f1
                              grads, stream);
 }
 
-// host-only self-test of this family's exact-f32 job table (tests/test_host.py)
+// host-only self-test of this family's exact-f32 group table (tests/test_host.py)
 extern "C" int nf_selftest_dw_tables_lcode_f32(void) {
-    NfDwJob jobs[NF_LC_DW_JOBS];
-    nf_lcode_build_dw_jobs(jobs);
+    NfDwGroup groups[NF_LC_DW_GROUPS];
+    nf_lcode_build_dw_groups(groups);
     const long lcode = 256L * 64 + 4L * 65536 + 128L * 272 + 4L * 128 + 4L * 256 + 5 * 256 + 128 + 4;
-    return nf_check_dw_jobs(jobs, NF_LC_DW_JOBS, nlc::SLAB_FLOATS, lcode);
+    int rc = nf_check_dw_groups(groups, NF_LC_DW_GROUPS, nlc::SLAB_FLOATS, lcode);
+    if (rc) return rc;
+    for (int64_t n : {(int64_t)131072, (int64_t)262144, (int64_t)259969, (int64_t)512}) {
+        int first[NF_DW_MAX_GROUPS + 1];
+        const int most = nf_dw_plan_groups(groups, NF_LC_DW_GROUPS, n, first);
+        NfReduceAlt alt;
+        if (first[NF_LC_DW_GROUPS] > 256 || most < 1 || !nf_dw_reduce_alt(groups, NF_LC_DW_GROUPS, most, &alt) || alt.n_slices != 0) return -200;
+    }
+    return 0;
 }

@@ -122,7 +122,7 @@ def test_lcode_mlp_bwd_vs_fp64_oracle(hip_lib, gpu, n_rays, s, precision):
     print(f"lcode mlp bwd ({n_rays}x{s}, {precision}): worst param rel L2 {worst:.2e}, latent {e:.2e}, mask flips {flips}")
     assert e < tol_g
     if precision != "f32":         # the bit masks the chain reads == the signs of the saved post-ReLU activations
-        mk = sv[LC_MASK_OFF * n_pts:].view(torch.int32).view(5, n_pts, 2, 4)
+        mk = sv[LC_MASK_OFF * n_pts:(LC_MASK_OFF + 40) * n_pts].view(torch.int32).view(5, n_pts, 2, 4)   # (the buffer ends in one tile of padding)
         x0 = sec("x0")
         nt, r, hh = 3, 5, 1
         feat = 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * hh
