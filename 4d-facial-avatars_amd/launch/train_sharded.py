@@ -71,7 +71,9 @@ def main(argv=None):
     groups = [{"params": trainable}]
     if background is not None:
         groups.append({"params": background, "lr": cfg.optimizer.lr})          # inert 2nd group, kept for checkpoint compatibility
-    optimizer = getattr(torch.optim, cfg.optimizer.type)(groups, lr=cfg.optimizer.lr)
+    # TR:193-199 `getattr(torch.optim, cfg.optimizer.type)`; nerf.optim holds one-launch forms of the same update rule (Adam) with
+    # torch's state layout, so checkpoints stay interchangeable with the reference's
+    optimizer = (getattr(nerf.optim, cfg.optimizer.type, None) or getattr(torch.optim, cfg.optimizer.type))(groups, lr=cfg.optimizer.lr)
     start_iter = 0
     if args.load_checkpoint and os.path.exists(args.load_checkpoint):
         ck = torch.load(args.load_checkpoint, map_location=dev)

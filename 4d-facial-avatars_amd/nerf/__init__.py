@@ -10,6 +10,7 @@ from .load_blender import load_blender_data
 from .load_flame import load_flame_data
 from .load_llff import load_llff_data
 from . import models
+from . import optim            # MI355X extension: nerf.optim.Adam = torch.optim.Adam's update for all tensors of a step in one launch
 from .models import *  # noqa: F401,F403
 from .nerf_helpers import *  # noqa: F401,F403
 from .nerf_helpers import (choose_rays, cumprod_exclusive, dump_rays, get_embedding_function, get_minibatches, get_ray_batch, get_ray_bundle, img2mse,

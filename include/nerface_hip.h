@@ -316,6 +316,14 @@ int nf_render_rays_fwd_f16(const float* packed_coarse, const void* packed_f16_co
                            float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
                            float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
 
+/* ---- optimizer step of the trainer -- replaces torch.optim.Adam.step() over [coarse model, fine model, latent codes]
+ *      (train_transformed_rays.py:193-199, 391-392) for all tensors in one launch.  Host arrays of n_tensors device pointers
+ *      (contiguous f32, numel[i] elements each); step = 1-based count of this update; torch's arithmetic (no weight decay,
+ *      no amsgrad): m += (1-b1)(g-m); v = b2 v + (1-b2) g g; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).            */
+int nf_adam_step(float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                 const int64_t* numel, int n_tensors, float lr, float beta1, float beta2, float eps, int64_t step,
+                 nf_stream_t stream);
+
 /* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
 int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);
 

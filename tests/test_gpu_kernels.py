@@ -350,3 +350,43 @@ def test_weighted_choice_breaks_ties_by_index(hip_lib, gpu):
     got = [ops.weighted_choice(w.to(gpu), n, u=u.to(gpu)).cpu() for _ in range(3)]
     assert torch.equal(got[0], want), int((got[0] != want).sum())
     assert torch.equal(got[0], got[1]) and torch.equal(got[0], got[2])
+
+
+def test_one_launch_adam_follows_torch_adam(hip_lib, gpu):
+    """nerf.optim.Adam (nf_adam_step: every tensor of a step in one launch) against torch.optim.Adam on the same parameters and
+    gradients: ragged sizes (the vector path and the scalar tail), a parameter without gradient (skipped, like layers_dir.3), a
+    learning-rate change between steps (the trainer decays lr every iteration), and the state layout -- a state_dict saved by one
+    loads into the other and both continue in step."""
+    import nerf
+    g = torch.Generator().manual_seed(5)
+    shapes = [(256, 171), (256,), (3, 128), (1,), (1000, 32), (7, 5), (128, 280)]
+    base = [torch.randn(s, generator=g) * 0.1 for s in shapes]
+    mk = lambda: [torch.nn.Parameter(b.clone().to(gpu)) for b in base]
+    pa, pb = mk(), mk()
+    oa = nerf.optim.Adam(pa, lr=5e-4)
+    ob = torch.optim.Adam(pb, lr=5e-4)
+    for it in range(6):
+        lr = 5e-4 * (0.1 ** (it / 250000.0)) if it else 5e-4
+        for o in (oa, ob):
+            for grp in o.param_groups:
+                grp["lr"] = lr
+        for k, (a, b) in enumerate(zip(pa, pb)):
+            if k == 3 and it % 2:                                   # a tensor that sometimes has no gradient
+                a.grad = b.grad = None
+                continue
+            gr = (torch.randn(shapes[k], generator=g) * (10.0 ** -(k % 4))).to(gpu)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+        if it == 2:                                                 # cross-load the optimizer state (checkpoint compatibility, both ways)
+            sa, sb = oa.state_dict(), ob.state_dict()
+            assert set(sa["state"][0]) == set(sb["state"][0]) == {"step", "exp_avg", "exp_avg_sq"}
+            oa.load_state_dict(sb)
+            ob.load_state_dict(sa)
+    for k, (a, b) in enumerate(zip(pa, pb)):
+        err = float((a - b).abs().max() / (b.abs().max() + 1e-12))
+        assert err < 2e-6, (k, err)
+        assert float((a.detach().cpu() - base[k]).abs().max()) > 0         # the parameters did move
+    assert float(oa.state[pa[3]]["step"]) == 3.0 and float(oa.state[pa[0]]["step"]) == 6.0
+    with pytest.raises(NotImplementedError):
+        nerf.optim.Adam(mk(), lr=1e-3, weight_decay=0.1)
