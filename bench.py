@@ -530,7 +530,27 @@ def device_info(dev):
         except Exception:
             mhz = 0.0
     cus = int(p.multi_processor_count)
-    return {"name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": cus, "engine_clock_mhz": mhz,
+    # what THIS box's HBM does right now (GPU boxes of the pool differ: one ran every store-heavy kernel 2x slower, profiles/r03_experiments.md §7):
+    # a 1 GiB fill (pure writes) and a 1 GiB copy (read + write) with torch's own kernels, best of 5
+    probe = {}
+    try:
+        x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+        y = torch.empty_like(x)
+        for name, fn, nbytes in (("hbm_fill_gbs", lambda: x.fill_(1.0), x.numel() * 4), ("hbm_copy_gbs", lambda: y.copy_(x), 2 * x.numel() * 4)):
+            best = 0.0
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                best = max(best, nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
+            probe[name] = best
+        del x, y
+        torch.cuda.empty_cache()
+    except Exception as e:
+        probe = {"hbm_probe_error": repr(e)}
+    return {**probe, "name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": cus, "engine_clock_mhz": mhz,
             "hbm_gib": round(p.total_memory / 2 ** 30, 1),
             "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
 
