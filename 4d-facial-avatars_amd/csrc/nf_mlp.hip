@@ -18,7 +18,15 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
 #include "nf_pack.h"
+
+#ifndef NF_FWD_PERSIST
+#define NF_FWD_PERSIST 1
+#endif
+#ifndef NF_FWD_STREAM
+#define NF_FWD_STREAM 1      // 0: the round-2 inference kernel (block epilogue per layer), kept as the A/B ablation of profiles/r03_mlp_f32_pmc.md
+#endif
 
 // =================================================================================================
 // pack: gather the 26 nn.Parameter storages into the fragment-ordered image
@@ -172,17 +180,30 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // =================================================================================================
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
-k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
+k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond_, const float* __restrict__ ro,
                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z,
                 int64_t n_points, int S, float* __restrict__ raw) {
     using namespace nfl;
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+#if NF_FWD_PERSIST
+    // persistent form: one workgroup per CU walks the point blocks with the grid's stride (no workgroup dispatch between blocks)
+#pragma unroll 1
+    for (int64_t blk = blockIdx.x;; blk += gridDim.x) {
+    const int64_t p0 = (blk * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) break;                        // wave-uniform; no barriers anywhere below
+    int opaque0 = 0;                                  // per-block opaque zero: the weight / bias loads must stay where the layers issue them
+    asm volatile("" : "+s"(opaque0));
+    const f32x4* W = reinterpret_cast<const f32x4*>(packed) + opaque0;
+    const float* cond = cond_ + opaque0;
+#else
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;                       // wave-uniform; no barriers anywhere below
-    f32x4* act4 = lds + wave * (16 * NT * 64);
     const f32x4* W = reinterpret_cast<const f32x4*>(packed);
+    const float* cond = cond_;
+#endif
 
     // ---- inputs: pts = ro + rd*z (T:78), PE fragments, dir fragment -----------------------------
     f32x4 pe[NT][4];
@@ -204,6 +225,88 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
 
     f32x4 acc[NT][16];
+#if NF_FWD_STREAM
+    // Layer-streamed form (nf_mlp_stream.h): every layer ends in nf_tail, which writes the raw accumulators to the slab tile by
+    // tile under the last chunk's MFMAs and fetches the next layer's bias, first weights and first B fragment; every layer starts
+    // with the bias as the C operand of its first MFMAs; the ReLU is applied where the slab is read.
+    NfStream<NT> st;
+    const NfW Wi = nf_w_image(reinterpret_cast<const float*>(W), PACKED_FLOATS), Ci = nf_w_image(cond, COND_FLOATS);
+    f32x4 bj[NT];
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    // ---- layers_xyz.0 : PE(64 slots) -> 256 ------------------------------------------------------------
+    nf_load_bias<16>(st.bias, Ci, B_L0, lane);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_L1 / 4, Ci, B_L1, act4, lane);
+    }
+    // ---- layers_xyz.1, .2 (ReLU of the previous layer on read) ------------------------------------------
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L1 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L2 / 4, Ci, B_L2, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L2 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 0>(acc, st.wb, bj, st, Wi, OFF_L3 / 4, Ci, B_L3, act4, lane);
+    // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ----------------------------------------
+    NF_PE_B(0); nf_chunk<NT, 16, true>(acc, st.wa, bj, st.bias);
+    nf_load_w16<16>(st.wa, Wi, OFF_L3 / 4 + 4 * 16 * 64, lane);            // the first slab chunk, three chunks ahead
+    nf_read_b<NT, false>(st.b0, act4, lane, 0);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+    }
+    nf_seg_lds<NT, 16, false, true>(acc, st, Wi, OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L4 / 4, Ci, B_L4, act4, lane);
+    // ---- layers_xyz.4, .5 --------------------------------------------------------------------------------
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L4 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L5 / 4, Ci, B_L5, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L5 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
+    // ---- fc_feat (no activation, M:250: layers_dir.0 reads it as stored) -----------------------------------
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 9, 1>(acc, st.wb, bj, st, Wi, OFF_D0 / 4, Ci, B_D0, act4, lane);
+    // ---- layers_dir.0 : [feat | dir slots] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2) -----------------------
+    float sigma_raw[NT];
+    {
+        f32x4 wd[16];
+        nf_load_w16<9>(wd, Wi, OFF_D0 / 4 + 16 * 9 * 64, lane);             // the dir-slot chunk's weights, a layer ahead
+        nf_seg_lds<NT, 9, true, false>(acc, st, Wi, OFF_D0 / 4, 16, act4, lane);
+        nf_pending_b<NT, false>(bj, st);
+        nf_chunk<NT, 9, false>(acc, st.wb, bj, st.bias);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_tail<NT, 9, 8, 8, 1>(acc, wd, bj, st, Wi, OFF_D1 / 4, Ci, B_D1, act4, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
+    }
+    // ---- layers_dir.1, .2 -----------------------------------------------------------------------------------
+    nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D1 / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 8, 8, 8, 1>(acc, st.wb, bj, st, Wi, OFF_D2 / 4, Ci, B_D2, act4, lane);
+    nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D2 / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+#undef NF_PE_B
+    // ---- fc_rgb -------------------------------------------------------------------------------------------
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
+#else
 #define NF_FINISH_LAYER(NO_, RELU_, SEC_, WIDTH_)                                                   \
     do {                                                                                            \
         if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                   \
@@ -255,6 +358,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     // ---- fc_rgb -------------------------------------------------------------------------------------------
     nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
     nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
+#endif
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -263,6 +367,9 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
                 reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
         }
     }
+#if NF_FWD_PERSIST
+    }
+#endif
 }
 
 // Training forward (exact f32): the same arithmetic as k_paper_mlp_fwd, plus everything the backward needs in `saved`
@@ -381,6 +488,16 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
     }
 }
 
+static int64_t nf_cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n = v;
+    }
+    return n;
+}
+
 static int nf_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
@@ -396,7 +513,7 @@ static int nf_launch_fwd(const float* packed, const float* cond, const float* ro
         hipLaunchKernelGGL((k_paper_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
-        hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+        hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)(NF_FWD_PERSIST ? (grid < nf_cu_count() ? grid : nf_cu_count()) : grid)), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
     NF_RETURN_LAUNCH();
 }

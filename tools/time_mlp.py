@@ -9,6 +9,14 @@ m = bench.synth_params(1, dev)
 hw = m.hip_weights()
 cond = ops.paper_condition(hw.get(), torch.randn(76, device=dev) * 0.5, torch.randn(32, device=dev) * 0.1, 0.2, 0.8)
 ro, rd = nerf.get_ray_bundle(512, 512, bench.INTRINSICS, bench.frame_pose(0).to(dev))
+if os.environ.get("TIME_MLP_HASH"):                # bit-level fingerprint of the f32 forward (A/B of kernel variants across processes)
+    import hashlib
+    torch.manual_seed(7)
+    for n_rays, S in ((1000, 37), (4096, 64), (3, 5)):
+        ro_, rd_ = ro.view(-1, 3)[:n_rays].contiguous(), rd.view(-1, 3)[:n_rays].contiguous()
+        z = torch.sort(torch.rand((n_rays, S), device=dev) * 0.6 + 0.2, dim=-1)[0].contiguous()
+        raw = ops.paper_mlp_fwd(hw.get(), cond, ro_, rd_, z)
+        print(f"hash f32 {n_rays}x{S}: {hashlib.sha1(raw.cpu().numpy().tobytes()).hexdigest()}  sum {raw.double().sum().item():.9e}  finite {bool(torch.isfinite(raw).all())}")
 for n_rays, S in ((65536, 192), (65536, 64)):
     ro_, rd_ = ro.view(-1, 3)[:n_rays].contiguous(), rd.view(-1, 3)[:n_rays].contiguous()
     z = torch.sort(torch.rand((n_rays, S), device=dev) * 0.6 + 0.2, dim=-1)[0].contiguous()
