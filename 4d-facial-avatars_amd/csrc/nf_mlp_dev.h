@@ -59,12 +59,34 @@ struct NfNoSide {
     static constexpr int N_STORE = 0, N_READ = 0;
 };
 
+// Weight fragments of a K chunk through a buffer descriptor over the layer's section: the per-lane part of the address is ONE VGPR
+// (lane * 16 + a multiple of 1 KiB, four values kept in registers) and the chunk offset is scalar -- against a 64-bit vector address
+// plus a v_add_co / v_addc pair per four loads in the global form.  In a one-wave-per-SIMD MFMA loop that vector arithmetic and the
+// wider VMEM issue are not free: the f32 inference kernel went from 91.6 to 86.7 ms per fine launch on this change alone
+// (profiles/r03_mlp_f32_stream.md).
+#ifndef NF_TRAIN_WBUF
+#define NF_TRAIN_WBUF 1
+#endif
+typedef unsigned nf_u32x4_ __attribute__((ext_vector_type(4)));
+template <int NO>
+__device__ __forceinline__ void nf_load_w_buf(f32x4 (&w)[NO], __amdgpu_buffer_rsrc_t rsrc, int chunk, int lane) {
+#pragma unroll
+    for (int no = 0; no < NO; ++no)
+        w[no] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane * 16 + (no & 3) * 1024, chunk * (NO * 1024) + (no >> 2) * 4096, 0));
+}
+
 template <int NT, int NO, class Side>
 __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4,
                                                      int lane, Side& side) {
     const int g = lane >> 4, c = lane & 15;
     f32x4 wa[NO], wb[NO], b0[NT], b1[NT];
-    nf_load_w<NT, NO>(wa, wsec, lane);
+#if NF_TRAIN_WBUF
+    const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(wsec), (short)0, nch * (NO * 1024), 0x00020000);
+#define NF_LOADW_(dst, chunk) nf_load_w_buf<NO>(dst, wr, chunk, lane)
+#else
+#define NF_LOADW_(dst, chunk) nf_load_w<NT, NO>(dst, wsec + (size_t)(chunk) * NO * 64, lane)
+#endif
+    NF_LOADW_(wa, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = act4[nf_act_idx4(16 * t + c, g)];
     __builtin_amdgcn_sched_barrier(0);
@@ -73,7 +95,7 @@ __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const
         // ---- half 1
 #pragma unroll
         for (int t = 0; t < NT; ++t) b1[t] = act4[nf_act_idx4(16 * t + c, 4 * (ni + 1) + g)];
-        nf_load_w<NT, NO>(wb, wsec + (size_t)(ni + 1) * NO * 64, lane);
+        NF_LOADW_(wb, ni + 1);
         nf_mma_chunk<NT, NO>(acc, wa, b0);
         side.half1(ni >> 1);
         __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);                              // the next fragment's LDS reads first
@@ -90,7 +112,7 @@ __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const
 #pragma unroll
         for (int t = 0; t < NT; ++t) b0[t] = act4[nf_act_idx4(16 * t + c, 4 * nx + g)];
         side.half2(ni >> 1);
-        nf_load_w<NT, NO>(wa, wsec + (size_t)nx * NO * 64, lane);
+        NF_LOADW_(wa, nx);
         nf_mma_chunk<NT, NO>(acc, wb, b1);
         __builtin_amdgcn_sched_group_barrier(0x100, NT + Side::N_READ, 0);
 #pragma unroll
@@ -100,6 +122,7 @@ __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const
         }
         __builtin_amdgcn_sched_barrier(0);
     }
+#undef NF_LOADW_
 }
 
 // Inference kernels: the plain loop, weights register double-buffered one chunk ahead, scheduled by the compiler.  Measured on
