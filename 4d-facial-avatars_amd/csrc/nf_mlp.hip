@@ -256,7 +256,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ----------------------------------------
     NF_PE_B(0); nf_chunk<NT, 16, true>(acc, st.wa, bj, st.bias);
     nf_load_w16<16>(st.wa, Wi, OFF_L3 / 4 + 4 * 16 * 64, lane);            // the first slab chunk, three chunks ahead
-    nf_read_b<NT, false>(st.b0, act4, lane, 0);
+    nf_read_b<NT>(st.b0, act4, lane, 0);
     {
         f32x4 w[16];
         nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 1 * 16 * 64, lane);
@@ -421,63 +421,121 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
         for (int k = 0; k < 16 * NT / 4; ++k) nf_copy_rows<16>(act4, cp, k, lane);
     }
 
+    // Layer-streamed like the inference kernel (nf_mlp_stream.h): bias as the C operand, the layer boundary under the last chunk's
+    // MFMAs (raw accumulators to the slab), the next layer prefetched.  Everything the backward needs is produced where the slab is
+    // READ, inside the K loops: the loop that consumes a layer's output applies the ReLU to its B fragments, collects their [x > 0]
+    // bits (nf_mask_bits -- a lane reads back exactly the elements it wrote) and carries the copy of the slab to `saved`, ReLU
+    // applied on the way out (NfCopyH: four whole-line stores per step of two chunks).
     f32x4 acc[NT][16];
-    uint2 m[NT];
-#define NF_FINISH_SAVE(NO_, MASKL_)                                                                  \
+    uint64_t m64[NT];
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    const NfW Wi = nf_w_image(packed, PACKED_FLOATS), Ci = nf_w_image(cond, COND_FLOATS);
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    // the last chunk's fragment (+ its mask bits), then the finished mask words of layer MASKL_ (the layer whose output was just consumed)
+#define NF_PENDING(RELU_, MASKL_, NCH_)                                                              \
     do {                                                                                            \
+        nf_pending_b<NT, RELU_>(bj, st);                                                            \
         if ((MASKL_) >= 0) {                                                                        \
-            nf_relu_with_mask<NT, NO_>(acc, m);                                                     \
+            nf_mask_bits<NT>(m64, st.bp, (NCH_) - 2);                                               \
+            nf_mask_bits<NT>(m64, bj, (NCH_) - 1);                                                  \
             _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
-                if (p0 + 16 * t < n) *nf_mask_ptr(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t];    \
+                if (p0 + 16 * t < n)                                                                \
+                    *nf_mask_ptr(saved, n, MASKL_, (p0 >> 4) + t, lane) = make_uint2((uint32_t)m64[t], (uint32_t)(m64[t] >> 32)); \
         }                                                                                           \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                              \
     } while (0)
-    // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
-    NF_FINISH_SAVE(16, 0);
-    // ---- layers_xyz.1, .2 (each K loop also streams the previous layer's output to `saved`) -------
-    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L1 / 4, 16, act4, lane, sec(S_H0, 256));
-    NF_FINISH_SAVE(16, 1);
-    nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L2 / 4, 16, act4, lane, sec(S_H1, 256));
-    NF_FINISH_SAVE(16, 2);
+    // one 256-wide layer from the slab: the slab = section SEC_ (ReLU layer MASKL_, or -1: as stored) is copied out and consumed
+#define NF_LAYER256(OFF_, FIRST_, SEC_, MASKL_, OFF_NEXT_, B_NEXT_, NO_NEXT_, NEXT_B_)                                    \
+    do {                                                                                                                   \
+        NfCopyH<64, 4, ((MASKL_) >= 0)> cs{act4, sec(SEC_, 256), lane, 8, {}};                                             \
+        cs.prime();                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) m64[t] = 0;                                                         \
+        nf_seg_lds<NT, 16, FIRST_, ((MASKL_) >= 0), ((MASKL_) >= 0)>(acc, st, Wi, OFF_, 16, act4, lane, cs, m64);          \
+        NF_PENDING(((MASKL_) >= 0), MASKL_, 16);                                                                           \
+        nf_tail<NT, 16, 16, NO_NEXT_, NEXT_B_>(acc, st.wb, bj, st, Wi, OFF_NEXT_, Ci, B_NEXT_, act4, lane);               \
+    } while (0)
+    // ---- layers_xyz.0 : PE(64 slots) -> 256 ------------------------------------------------------------
+    nf_load_bias<16>(st.bias, Ci, B_L0, lane);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_L1 / 4, Ci, B_L1, act4, lane);
+    }
+    // ---- layers_xyz.1, .2 (each K loop also streams the layer output it consumes to `saved`) -------------
+    NF_LAYER256(OFF_L1 / 4, true, S_H0, 0, OFF_L2 / 4, B_L2, 16, 1);
+    NF_LAYER256(OFF_L2 / 4, true, S_H1, 1, OFF_L3 / 4, B_L3, 16, 0);
     // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane, sec(S_H2, 256));
-    NF_FINISH_SAVE(16, 3);
-    // ---- layers_xyz.4, .5 ------------------------------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L4 / 4, 16, act4, lane, sec(S_H3, 256));
-    NF_FINISH_SAVE(16, 4);
-    nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_L5 / 4, 16, act4, lane, sec(S_H4, 256));
-    NF_FINISH_SAVE(16, 5);
-    // ---- fc_feat (no activation, M:250) ------------------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_FEAT / 4, 16, act4, lane, sec(S_H5, 256));
-    NF_FINISH_SAVE(16, -1);
-    // ---- layers_dir.0 : [feat | dir slots] -> 128, ReLU; tile 8 row 0 = fc_alpha(feat) (Q2) ----------
-    nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
-    nf_mma_from_lds_copy<NT, 9, 64, 4>(acc, W + OFF_D0 / 4, 16, act4, lane, sec(S_FEAT, 256));
-    nf_mma_from_regs<NT, 9, 1>(acc, W + OFF_D0 / 4 + 16 * 9 * 64, dirf, lane);
+    NF_PE_B(0); nf_chunk<NT, 16, true>(acc, st.wa, bj, st.bias);
+    nf_load_w16<16>(st.wa, Wi, OFF_L3 / 4 + 4 * 16 * 64, lane);            // the first slab chunk, three chunks ahead
+    nf_read_b<NT>(st.b0, act4, lane, 0);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+    }
+    NF_LAYER256(OFF_L3 / 4 + 4 * 16 * 64, false, S_H2, 2, OFF_L4 / 4, B_L4, 16, 1);
+    // ---- layers_xyz.4, .5, fc_feat (no activation, M:250) -----------------------------------------
+    NF_LAYER256(OFF_L4 / 4, true, S_H3, 3, OFF_L5 / 4, B_L5, 16, 1);
+    NF_LAYER256(OFF_L5 / 4, true, S_H4, 4, OFF_FEAT / 4, B_FEAT, 16, 1);
+    NF_LAYER256(OFF_FEAT / 4, true, S_H5, 5, OFF_D0 / 4, B_D0, 9, 1);
+    // ---- layers_dir.0 : [feat | dir slots] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2) -------------------
     float sigma_raw[NT];
+    {
+        f32x4 wd[16];
+        nf_load_w16<9>(wd, Wi, OFF_D0 / 4 + 16 * 9 * 64, lane);             // the dir-slot chunk's weights, a layer ahead
+        NfCopyH<64, 4, false> cs{act4, sec(S_FEAT, 256), lane, 8, {}};
+        cs.prime();
+        nf_seg_lds<NT, 9, true, false, false>(acc, st, Wi, OFF_D0 / 4, 16, act4, lane, cs, m64);
+        NF_PENDING(false, -1, 16);
+        nf_chunk<NT, 9, false>(acc, st.wb, bj, st.bias);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
-    NF_FINISH_SAVE(8, 6);
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_tail<NT, 9, 8, 8, 1>(acc, wd, bj, st, Wi, OFF_D1 / 4, Ci, B_D1, act4, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
+    }
     // ---- layers_dir.1, .2 (128-wide rows: two per copy instruction) -------------------------------------
-    nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
-    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, W + OFF_D1 / 4, 8, act4, lane, sec(S_D0, 128));
-    NF_FINISH_SAVE(8, 7);
-    nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
-    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, W + OFF_D2 / 4, 8, act4, lane, sec(S_D1, 128));
-    NF_FINISH_SAVE(8, 8);
-#undef NF_FINISH_SAVE
+    {
+        NfCopyH<32, 4, true> cs{act4, sec(S_D0, 128), lane, 4, {}};
+        cs.prime();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m64[t] = 0;
+        nf_seg_lds<NT, 8, true, true, true>(acc, st, Wi, OFF_D1 / 4, 8, act4, lane, cs, m64);
+        NF_PENDING(true, 6, 8);
+        nf_tail<NT, 8, 8, 8, 1>(acc, st.wb, bj, st, Wi, OFF_D2 / 4, Ci, B_D2, act4, lane);
+    }
+    {
+        NfCopyH<32, 4, true> cs{act4, sec(S_D1, 128), lane, 4, {}};
+        cs.prime();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m64[t] = 0;
+        nf_seg_lds<NT, 8, true, true, true>(acc, st, Wi, OFF_D2 / 4, 8, act4, lane, cs, m64);
+        NF_PENDING(true, 7, 8);
+        nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    }
     // ---- fc_rgb -------------------------------------------------------------------------------------------
-    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
-    nf_mma_from_lds_copy<NT, 1, 32, 4>(acc, W + OFF_RGB / 4, 8, act4, lane, sec(S_D2, 128));
+    {
+        NfCopyH<32, 4, true> cs{act4, sec(S_D2, 128), lane, 4, {}};
+        cs.prime();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m64[t] = 0;
+        nf_seg_lds<NT, 1, true, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane, cs, m64);
+        NF_PENDING(true, 8, 8);
+        nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
+    }
+#undef NF_LAYER256
+#undef NF_PENDING
+#undef NF_PE_B
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

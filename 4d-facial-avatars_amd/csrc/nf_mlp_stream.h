@@ -26,6 +26,7 @@ struct NfStream {
     f32x4 wa[16], wb[16];     // weight fragments of two consecutive K chunks
     f32x4 bias[16];           // the layer's bias fragments
     f32x4 b0[NT], b1[NT];     // B fragments of the same two chunks
+    f32x4 bp[NT];             // training forward: the fragment the previous half-iteration consumed, until its mask bits are taken
 };
 
 __device__ __forceinline__ f32x4 nf_relu_i(f32x4 v) {
@@ -38,33 +39,25 @@ __device__ __forceinline__ f32x4 nf_relu_i(f32x4 v) {
     return o;
 }
 
-#ifndef NF_FWD_WBUF
-#define NF_FWD_WBUF 1
-#endif
-
-// the packed weight image as the K loops address it: f32x4 index `off4` of a chunk (wave-uniform) + fragment no * 64 + lane
+// the packed weight image (or the per-call bias table) as the K loops address it: a buffer descriptor, so that the per-lane part of
+// an address is ONE VGPR (lane * 16 + a multiple of 1 KiB) and the chunk offset is scalar -- against a 64-bit vector address plus a
+// v_add_co / v_addc pair per four loads in the global form, which a one-wave-per-SIMD MFMA loop does not get for free
+// (91.6 -> 86.7 ms per fine launch on this change alone, profiles/r03_mlp_f32_stream.md)
 struct NfW {
-    const f32x4* p;
     __amdgpu_buffer_rsrc_t rsrc;
 };
-__device__ __forceinline__ NfW nf_w_image(const float* packed, int n_floats) {
+__device__ __forceinline__ NfW nf_w_image(const float* base, int n_floats) {
     NfW w;
-    w.p = reinterpret_cast<const f32x4*>(packed);
-    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(packed), (short)0, n_floats * 4, 0x00020000);
+    w.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), (short)0, n_floats * 4, 0x00020000);
     return w;
 }
 
+// weight fragments of one K chunk: f32x4 index `off4` of the chunk (wave-uniform) + fragment no * 64 + lane
 template <int NO>
 __device__ __forceinline__ void nf_load_w16(f32x4 (&w)[16], const NfW& W, unsigned off4, int lane) {
 #pragma unroll
-    for (int no = 0; no < NO; ++no) {
-#if NF_FWD_WBUF
-        // buffer form: one VGPR (lane * 16 + a 12-bit immediate) and a scalar offset per load -- no 64-bit vector address arithmetic
+    for (int no = 0; no < NO; ++no)
         w[no] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(W.rsrc, lane * 16 + (no & 3) * 1024, (int)(off4 * 16u) + (no >> 2) * 4096, 0));
-#else
-        w[no] = W.p[off4 + no * 64 + lane];
-#endif
-    }
 }
 
 // bias fragments of a layer: floats [off + 16 no + 4 g, + 4) of the per-call bias table `cond`
@@ -72,23 +65,15 @@ template <int NO>
 __device__ __forceinline__ void nf_load_bias(f32x4 (&bias)[16], const NfW& C, unsigned off, int lane) {
     const int g = lane >> 4;
 #pragma unroll
-    for (int no = 0; no < NO; ++no) {
-#if NF_FWD_WBUF
+    for (int no = 0; no < NO; ++no)
         bias[no] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(C.rsrc, g * 16 + no * 64, (int)(off * 4u), 0));
-#else
-        bias[no] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(C.p) + off + 16 * no + 4 * g);
-#endif
-    }
 }
 
-template <int NT, bool RELU>
+template <int NT>
 __device__ __forceinline__ void nf_read_b(f32x4 (&b)[NT], const f32x4* act4, int lane, int ni) {
     const int g = lane >> 4, c = lane & 15;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4 v = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
-        b[t] = RELU ? nf_relu_i(v) : v;
-    }
+    for (int t = 0; t < NT; ++t) b[t] = act4[nf_act_idx4(16 * t + c, 4 * ni + g)];
 }
 
 // one K chunk; FIRST: the layer's first chunk, whose first MFMA per tile takes the bias as its C operand
@@ -109,7 +94,8 @@ __device__ __forceinline__ void nf_chunk(f32x4 (&acc)[NT][16], const f32x4 (&w)[
         else if ((n) == 2) __builtin_amdgcn_sched_group_barrier(mask, 2, 0);           \
         else if ((n) == 3) __builtin_amdgcn_sched_group_barrier(mask, 3, 0);           \
         else if ((n) == 4) __builtin_amdgcn_sched_group_barrier(mask, 4, 0);           \
-        else if ((n) == 8) __builtin_amdgcn_sched_group_barrier(mask, 8, 0);           \
+        else if ((n) == 5) __builtin_amdgcn_sched_group_barrier(mask, 5, 0);           \
+        else if ((n) == 6) __builtin_amdgcn_sched_group_barrier(mask, 6, 0);           \
     } while (0)
 
 // timing ablations (results invalid): no weight loads / no slab reads inside the K loops
@@ -119,73 +105,123 @@ __device__ __forceinline__ void nf_chunk(f32x4 (&acc)[NT][16], const f32x4 (&w)[
 #ifndef NF_ABL_NOLDS
 #define NF_ABL_NOLDS 0
 #endif
-#ifndef NF_FWD_LOOP_PIPE
-#define NF_FWD_LOOP_PIPE 1
-#endif
 
-// one half-iteration of the explicit pipeline: the MFMAs of a chunk (w, ReLU(raw)) with the fetches of the chunk after it
-// (weights -> wn, raw fragment -> rawn) placed among them: the LDS reads first, one weight load per output tile
-template <int NT, int NO, bool FIRST, bool RELU_IN>
+// What else rides in a K loop.  The inference kernel: nothing.  The training forward: the deferred copy of the slab the loop reads
+// (the previous layer's output) to `saved`, PER instructions per step -- the head chunk is step 0, loop iteration j is step j; the
+// rows of step j + 1 are read from LDS during step j and stored under the first chunk of step j + 1 (NfSlabCopy, nf_mlp_dev.h:
+// whole 128-byte lines, rows past n_points dropped by the descriptor's range check).  (nch / 2) * PER must equal the
+// 16 NT * W4 / 64 instructions the slab takes.  The slab holds the accumulators as they were (see nf_tail): RELU applies the
+// activation on the way out, so that `saved` has what the weight-gradient GEMMs read.
+struct NfNoCopy {
+    static constexpr int N = 0;
+    __device__ __forceinline__ void stores(int) const {}
+    __device__ __forceinline__ void reads(int) {}
+};
+
+template <int W4, int PER, bool RELU>
+struct NfCopyH {
+    const f32x4* act4;
+    NfSlabCopy cp;
+    int lane, n_step;
+    f32x4 cv[PER];
+    static constexpr int N = PER;
+    __device__ __forceinline__ void prime() {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, k, lane);
+    }
+    __device__ __forceinline__ void stores(int step) const {
+#pragma unroll
+        for (int k = 0; k < PER; ++k) nf_copy_write<W4>(RELU ? nf_relu_i(cv[k]) : cv[k], cp, step * PER + k, lane);
+    }
+    __device__ __forceinline__ void reads(int step) {                    // the rows of step + 1; past the last step: re-read (unused)
+        const int nx = step + 1 < n_step ? step + 1 : step;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) cv[k] = nf_copy_read<W4>(act4, nx * PER + k, lane);
+    }
+};
+
+// [x > 0] bits of a consumed fragment into the lane's 64-bit mask word of the layer that produced it: bit 4 ni + r of lane (g, c)
+// <-> feature 16 ni + 4 g + r of point 16 t + c (the order nf_relu_with_mask defined and the dX chain reads).  `b` is the fragment
+// after the ReLU: as integers, min(b, 1) is the bit.
+template <int NT>
+__device__ __forceinline__ void nf_mask_bits(uint64_t (&m64)[NT], const f32x4 (&b)[NT], int ni) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        uint32_t nib = 0u;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const uint32_t y = (uint32_t)__float_as_int(b[t][r]);
+            nib |= (y < 1u ? y : 1u) << r;                                  // v_min_u32, v_lshl_or_b32
+        }
+        m64[t] |= (uint64_t)nib << (4 * ni);
+    }
+}
+
+// one half-iteration of the pipeline: the MFMAs of a chunk (w, fragment raw -- ReLU applied here if RELU_IN) with the fetches of
+// the chunk after it (weights -> wn, fragment -> rawn) placed among them: the LDS reads first, one weight load per output tile;
+// ST / RD: the copy's stores / LDS reads of `step` ride along; MASK: the consumed fragment's ReLU bits are collected in m64
+template <int NT, int NO, bool FIRST, bool RELU_IN, bool MASK, bool ST, bool RD, class Side>
 __device__ __forceinline__ void nf_half(f32x4 (&acc)[NT][16], const f32x4 (&w)[16], const f32x4 (&raw)[NT], f32x4 (&wn)[16], f32x4 (&rawn)[NT],
-                                        const f32x4 (&bias)[16], const NfW& W, unsigned wsrc, const f32x4* act4, int lane, int ni_next) {
+                                        const f32x4 (&bias)[16], const NfW& W, unsigned wsrc, const f32x4* act4, int lane, int ni_next, Side& side,
+                                        int step, uint64_t (&m64)[NT], f32x4 (&bp)[NT]) {
+    constexpr int NS = ST ? Side::N : 0, NR = RD ? Side::N : 0;
     f32x4 b[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(raw[t]) : raw[t];
-    nf_read_b<NT, false>(rawn, act4, lane, ni_next);
-    nf_load_w16<NO>(wn, W, wsrc, lane);
+    // mask bits: all taken in the half-iterations that carry the copy's stores (their vector work interleaves with the first MFMAs
+    // behind the LDS reads); the other half only parks its fragment -- with its own LDS reads and their addresses in front, its bit
+    // arithmetic ended up ahead of everything, in front of an idle matrix pipe
+    if (MASK && ST) {
+        if (!RD) nf_mask_bits<NT>(m64, bp, ni_next - 2);            // (the head chunk, ST and RD, has no predecessor)
+        nf_mask_bits<NT>(m64, b, ni_next - 1);
+    }
+    if (MASK && !ST) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bp[t] = b[t];
+    }
+    if (!NF_ABL_NOLDS || FIRST) nf_read_b<NT>(rawn, act4, lane, ni_next);
+    const Side rows = side;                       // (the rows this half stores: a head chunk also reads the next ones over them)
+    if (RD) side.reads(step);                     // (source order = the order the groups below ask for: LDS reads, loads, stores)
+    if (!NF_ABL_NOLOAD || FIRST) nf_load_w16<NO>(wn, W, wsrc, lane);
+    if (ST) rows.stores(step);
     nf_chunk<NT, NO, FIRST>(acc, w, b, bias);
-    __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
-#if NF_FWD_LOOP_PIPE == 2
-    // burst form: all fetches of the next chunk at the top of this one (a full chunk ahead), then the MFMAs back to back
-    __builtin_amdgcn_sched_group_barrier(0x020, NO, 0);
-    if (RELU_IN) __builtin_amdgcn_sched_group_barrier(0x002, 4 * NT, 0);
-    __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT * NO, 0);
-#else
+    NF_SGB_N(0x100, NT + NR);
     if (RELU_IN) __builtin_amdgcn_sched_group_barrier(0x002, 4 * NT, 0);
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
         __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        NF_SGB_N(0x040, (no + 1) * NS / NO - no * NS / NO);
     }
-#endif
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// The first nch - 1 of nch slab chunks of a layer (nch even).  Entry: st.wa / st.b0 hold chunk 0 (the fragment as stored: the ReLU,
-// if any, is applied where it is consumed).  Exit: chunk nch - 1 is pending in st.wb / st.b1 -- the caller runs it with nf_tail
-// (the layer ends there) or nf_chunk, through nf_pending_b.
+// The first nch - 1 of nch slab chunks of a layer (nch even).  Entry: st.wa / st.b0 hold chunk 0 (the fragment as stored).  Exit:
+// chunk nch - 1 is pending in st.wb / st.b1 -- the caller runs it with nf_tail (the layer ends there) or nf_chunk, through nf_pending_b.
+template <int NT, int NO, bool FIRST, bool RELU_IN, bool MASK, class Side>
+__device__ __forceinline__ void nf_seg_lds(f32x4 (&acc)[NT][16], NfStream<NT>& st, const NfW& W, unsigned wsec, int nch, const f32x4* act4,
+                                           int lane, Side& side, uint64_t (&m64)[NT]) {
+    if (MASK) {                                   // (the first loop iteration finds no parked fragment: all zero = no bits)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.bp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nf_half<NT, NO, FIRST, RELU_IN, MASK, true, true>(acc, st.wa, st.b0, st.wb, st.b1, st.bias, W, wsec + NO * 64, act4, lane, 1, side, 0, m64, st.bp);
+#pragma unroll 1
+    for (int ni = 1; ni < nch - 1; ni += 2) {
+        const int step = (ni + 1) >> 1;
+        nf_half<NT, NO, false, RELU_IN, MASK, true, false>(acc, st.wb, st.b1, st.wa, st.b0, st.bias, W, wsec + (ni + 1) * NO * 64, act4, lane, ni + 1, side,
+                                                           step, m64, st.bp);
+        nf_half<NT, NO, false, RELU_IN, MASK, false, true>(acc, st.wa, st.b0, st.wb, st.b1, st.bias, W, wsec + (ni + 2) * NO * 64, act4, lane, ni + 2, side,
+                                                           step, m64, st.bp);
+    }
+}
 template <int NT, int NO, bool FIRST, bool RELU_IN>
 __device__ __forceinline__ void nf_seg_lds(f32x4 (&acc)[NT][16], NfStream<NT>& st, const NfW& W, unsigned wsec, int nch, const f32x4* act4,
                                            int lane) {
-#if NF_FWD_LOOP_PIPE
-    __builtin_amdgcn_sched_barrier(0);
-    nf_half<NT, NO, FIRST, RELU_IN>(acc, st.wa, st.b0, st.wb, st.b1, st.bias, W, wsec + NO * 64, act4, lane, 1);
-#pragma unroll 1
-    for (int ni = 1; ni < nch - 1; ni += 2) {
-        nf_half<NT, NO, false, RELU_IN>(acc, st.wb, st.b1, st.wa, st.b0, st.bias, W, wsec + (ni + 1) * NO * 64, act4, lane, ni + 1);
-        nf_half<NT, NO, false, RELU_IN>(acc, st.wa, st.b0, st.wb, st.b1, st.bias, W, wsec + (ni + 2) * NO * 64, act4, lane, ni + 2);
-    }
-#else
-    f32x4 b[NT];
-    nf_load_w16<NO>(st.wb, W, wsec + NO * 64, lane);
-    nf_read_b<NT, false>(st.b1, act4, lane, 1);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(st.b0[t]) : st.b0[t];
-    nf_chunk<NT, NO, FIRST>(acc, st.wa, b, st.bias);
-#pragma unroll 1
-    for (int ni = 1; ni < nch - 1; ni += 2) {
-        if (!NF_ABL_NOLOAD) nf_load_w16<NO>(st.wa, W, wsec + (ni + 1) * NO * 64, lane);
-        if (!NF_ABL_NOLDS) nf_read_b<NT, false>(st.b0, act4, lane, ni + 1);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(st.b1[t]) : st.b1[t];
-        nf_chunk<NT, NO, false>(acc, st.wb, b, st.bias);
-        if (!NF_ABL_NOLOAD) nf_load_w16<NO>(st.wb, W, wsec + (ni + 2) * NO * 64, lane);
-        if (!NF_ABL_NOLDS) nf_read_b<NT, false>(st.b1, act4, lane, ni + 2);
-#pragma unroll
-        for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(st.b0[t]) : st.b0[t];
-        nf_chunk<NT, NO, false>(acc, st.wa, b, st.bias);
-    }
-#endif
+    NfNoCopy none;
+    uint64_t unused[NT];
+    nf_seg_lds<NT, NO, FIRST, RELU_IN, false>(acc, st, W, wsec, nch, act4, lane, none, unused);
 }
 
 // the pending chunk's fragment as the MFMAs take it
@@ -195,11 +231,11 @@ __device__ __forceinline__ void nf_pending_b(f32x4 (&b)[NT], const NfStream<NT>&
     for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(st.b1[t]) : st.b1[t];
 }
 
-
 // The layer's last K chunk (weights w, fragments b) and the layer boundary under it.  NO tiles are computed, the first NO_ST of
-// them go to the slab.  The next layer has NO_NEXT output tiles, weights at wnext, bias at bias_next; NEXT_B says how it starts:
-// 0 = not from the slab (register chunks), 1 = from the slab.  Leaves the next layer's
-// first weight chunk in st.wa, its bias in st.bias and (NEXT_B != 0) its first B fragment, as stored, in st.b0.
+// them go to the slab.  The next layer has NO_NEXT output tiles, weights at wnext, bias at bias_next; NEXT_B: 1 = it starts from
+// the slab, 0 = from register chunks.  Leaves the next layer's first weight chunk in st.wa, its bias in st.bias and (NEXT_B) its
+// first B fragment, as stored, in st.b0.
+// The accumulators go to the slab as they are, straight from the accumulator registers: whoever reads the slab applies the ReLU.
 template <int NT, int NO, int NO_ST, int NO_NEXT, int NEXT_B>
 __device__ __forceinline__ void nf_tail(f32x4 (&acc)[NT][16], const f32x4 (&w)[16], const f32x4 (&b)[NT], NfStream<NT>& st,
                                         const NfW& W, unsigned wnext, const NfW& C, unsigned bias_next, f32x4* act4, int lane) {
