@@ -255,6 +255,34 @@ k_dw_gemm_lds(NfDwGroupSet gs, int slab_floats, const float* __restrict__ dz, co
     // Every lane keeps its 6 source pointers and advances them by one chunk per issue.  Lanes past a narrow panel's `valid`
     // columns re-read its last valid piece: those columns only feed output tiles nobody stores.
     const int dma_row = lane >> 5, dma_col = (lane & 31) * 4;
+#ifndef NF_DW_BUFFER_DMA
+#define NF_DW_BUFFER_DMA 1
+#endif
+#if NF_DW_BUFFER_DMA
+    // Buffer form of the DMA: per panel one descriptor based at the slice's first row, the lane's part of the address in ONE VGPR
+    // that never changes, and the chunk offset in an SGPR advanced by scalar adds -- no 64-bit vector address per panel, no
+    // v_add_co / v_addc per issue.
+    __amdgpu_buffer_rsrc_t rs[NF_DW_MAXP];
+    int voff[NF_DW_MAXP], soff[NF_DW_MAXP], step_b[NF_DW_MAXP];
+#pragma unroll
+    for (int s = 0; s < NF_DW_MAXP; ++s) {
+        const NfDwPanel pn = grp.panel[s];
+        const bool on = pn.kind >= 0;
+        const float* base = pn.kind == 1 ? d_raw : ((pn.kind == 0 ? dz : saved) + (int64_t)pn.sec * n_points);
+        const int ld = on ? pn.ld : 0;
+        const int col = on ? (dma_col < pn.valid ? dma_col : pn.valid - 4) : 0;
+        step_b[s] = 64 * ld;
+        soff[s] = 0;
+        voff[s] = on ? ((2 * wave + dma_row) * ld + pn.col0 + col) * 4 : 0;
+        rs[s] = __builtin_amdgcn_make_buffer_rsrc(on ? const_cast<float*>(base + p_begin * ld) : const_cast<float*>(nf_dw_zero16), (short)0, on ? -1 : 16,
+                                                  0x00020000);
+    }
+    auto issue_piece = [&](int s, int stage, bool advance) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs[s], (__attribute__((address_space(3))) void*)(lds + stage * NF_DW_STAGE_BYTES + wave * 1024 + s * NF_DW_PANEL_BYTES),
+                                                 16, voff[s], soff[s], 0, 0);
+        soff[s] += advance ? step_b[s] : 0;
+    };
+#else
     const char* src[NF_DW_MAXP];               // source of the NEXT chunk to issue
     int step_b[NF_DW_MAXP];                    // bytes per chunk (wave-uniform)
 #pragma unroll
@@ -276,6 +304,7 @@ k_dw_gemm_lds(NfDwGroupSet gs, int slab_floats, const float* __restrict__ dz, co
                                          16, 0, 0);
         src[s] += advance ? step_b[s] : 0;
     };
+#endif
     auto issue = [&](int stage, bool advance) {
 #pragma unroll
         for (int s = 0; s < NF_DW_MAXP; ++s) issue_piece(s, stage, advance);

@@ -816,7 +816,9 @@ def main():
                         "frac_executed": float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
                         "note": "achieved counts the ALGORITHMIC FLOPs of the reference MLP (1,100,032 per point); the kernel folds the per-frame "
                                 "constant input columns (expression, latent code, PE(near), PE(far)) into bias vectors and issues 999,936 "
-                                "MFMA FLOPs per point: executed_tflops / frac_executed (= the matrix pipe's busy fraction, PMC: profiles/r03_mlp_f32_pmc.md)"}}
+                                "MFMA FLOPs per point: executed_tflops / frac_executed (= the matrix pipe's busy fraction at the nominal clock; "
+                                "PMC of the round-2 kernel: profiles/r03_mlp_f32_pmc.md, the layer-streamed kernel: profiles/r03_mlp_f32_stream.md).  "
+                                "frac above 1 is not an error: the folded 9 % of the algorithmic FLOPs cost no matrix cycles"}}
         for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
             exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms[prec] * 1e-3) / 1e12
