@@ -25,7 +25,7 @@
 #define NF_FWD_PERSIST 1
 #endif
 #ifndef NF_FWD_STREAM
-#define NF_FWD_STREAM 1      // 0: the round-2 inference kernel (block epilogue per layer), kept as the A/B ablation of profiles/r03_mlp_f32_pmc.md
+#define NF_FWD_STREAM 1      // 0 (with NF_FWD_PERSIST=0): the round-2 inference kernel (block epilogue per layer), the A/B baseline of profiles/r03_mlp_f32_stream.md
 #endif
 
 // =================================================================================================

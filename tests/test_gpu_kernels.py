@@ -124,6 +124,30 @@ def test_paper_mlp_fwd(hip_lib, gpu, n_rays, s):
     assert torch.all(err.amax(dim=(0, 1)) <= 2e-5 * scale + 2e-5)
 
 
+def test_paper_mlp_fwd_persistent_grid_is_launch_invariant(hip_lib, gpu):
+    """The exact-f32 inference kernel runs a persistent grid (one workgroup per CU walks the 128-point blocks with the grid's stride).
+    Size-independent property: a launch with more blocks than the grid (700 x 67 = 46900 points = 367 blocks, the last one partial)
+    must give, bit for bit, what two smaller launches over the same rays give -- a point's result cannot depend on the block that
+    computed it, nor on which pass of the workgroup's loop that was."""
+    import nerf
+    from nerf import ops
+    c, ro, rd, z = _mlp_inputs(700, 67, 23)
+    m = nerf.models.ConditionalBlendshapePaperNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                        include_input_dir=False)
+    m.load_state_dict(c["p_fine"])
+    m.to(gpu)
+    pk = m.hip_weights().get()
+    cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    ro, rd, z = ro.to(gpu), rd.to(gpu), z.to(gpu)
+    big = ops.paper_mlp_fwd(pk, cond, ro, rd, z)
+    parts = [ops.paper_mlp_fwd(pk, cond, ro[a:b].contiguous(), rd[a:b].contiguous(), z[a:b].contiguous()) for a, b in ((0, 301), (301, 700))]
+    assert torch.isfinite(big).all()
+    assert torch.equal(big, torch.cat(parts, dim=0))
+    # and the training forward (not persistent, its own K loops) returns the same raw values
+    raw_t, _ = ops.paper_mlp_fwd_train(pk, cond, ro, rd, z)
+    assert torch.equal(raw_t, big)
+
+
 @pytest.mark.parametrize("n_rays,s,bgflag,noisy", [(9, 64, True, False), (4, 192, True, True), (7, 5, False, False), (3, 130, True, True)])
 def test_volume_render_fwd(hip_lib, gpu, n_rays, s, bgflag, noisy):
     from nerf import ops
