@@ -38,6 +38,25 @@ def stats(db):
     for (n, gx), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
         if sum(byk[n]) / tot > 0.01:
             print(f"| {n} | {gx} | {len(d)} | {sum(d)/len(d)/1e3:.1f} | {min(d)/1e3:.1f} | {max(d)/1e3:.1f} |")
+    # A persistent-grid kernel launches the same grid for every problem size: its launches are told apart by their durations.
+    print("\n## duration clusters (a new cluster where the sorted durations jump by more than 25 %), kernels above 1 % of the time\n")
+    print("| kernel | grid_x (threads) | cluster | calls | avg us | min us | max us |")
+    print("|---|---|---|---|---|---|---|")
+    for (n, gx), d in sorted(agg.items(), key=lambda kv: -sum(kv[1])):
+        if sum(byk[n]) / tot <= 0.01:
+            continue
+        d = sorted(d)
+        clusters, cur_c = [], [d[0]]
+        for x in d[1:]:
+            if x > 1.25 * cur_c[-1]:
+                clusters.append(cur_c)
+                cur_c = [x]
+            else:
+                cur_c.append(x)
+        clusters.append(cur_c)
+        if len(clusters) > 1:
+            for k, c in enumerate(clusters):
+                print(f"| {n} | {gx} | {k} | {len(c)} | {sum(c)/len(c)/1e3:.1f} | {min(c)/1e3:.1f} | {max(c)/1e3:.1f} |")
 
 
 def pmc(dbs):
