@@ -125,10 +125,11 @@ __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const
 #undef NF_LOADW_
 }
 
-// Inference kernels: the plain loop, weights register double-buffered one chunk ahead, scheduled by the compiler.  Measured on
-// the same box against the explicit pipeline above (profiles/r03_mlp_f32_pmc.md): 94.03 vs 94.74 ms per fine launch -- the
-// pipeline removes s_waitcnt time (4.9 % -> 3.1 % of the wave cycles) but its per-tile load / wait pairs cost as many issue slots,
-// so the inference path keeps this form and the training kernels (which need the Side hooks) use the pipeline.  nch must be even.
+// The plain loop, weights register double-buffered one chunk ahead, scheduled by the compiler: the K loop of the inference kernels that
+// are not layer-streamed yet (second model family, tiny_nerf, the pre-encoded entry).  The paper model's exact-f32 inference and
+// training-forward kernels use nf_mlp_stream.h (layer boundaries under the MFMAs, pipelined loop on buffer loads: 94.1 -> 85.9 ms per fine
+// launch, profiles/r03_mlp_f32_stream.md); on global loads this loop and the explicit pipeline above measured the same (94.03 vs 94.74 ms,
+// profiles/r03_mlp_f32_pmc.md).  nch must be even.
 template <int NT, int NO>
 __device__ __forceinline__ void nf_mma_from_lds(f32x4 (&acc)[NT][16], const f32x4* __restrict__ wsec, int nch, const f32x4* act4, int lane) {
     const int g = lane >> 4, c = lane & 15;
