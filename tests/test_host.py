@@ -308,3 +308,54 @@ def test_launcher_host_helpers():
     got = eval_sharded.jet_u8(x).tolist()
     want = [[[0, 0, 127], [0, 0, 255], [0, 255, 255]], [[127, 255, 127], [255, 255, 0], [127, 0, 0]]]
     assert got == want, got
+
+
+def test_hot_kernels_keep_their_register_and_instruction_budget(tmp_path):
+    """CPU (hipcc cross-compiles gfx950): the hand-scheduled exact-f32 kernels must keep the shape the measurements were taken on --
+    no spilled registers, no scratch, the 128 KiB of wave-private LDS slabs, the weight stream of the layer-streamed kernels as buffer
+    loads (no 64-bit vector addresses, no flat loads), and the weight-gradient kernel's DMA in buffer form.  A compiler or flag change
+    that breaks one of these costs 5-10 % of the headline without failing any numerical test."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
+    import build
+    src_dir = os.path.join(ROOT, "4d-facial-avatars_amd", "csrc")
+
+    def kernels(src):
+        out = str(tmp_path / (src + ".s"))
+        subprocess.run([hipcc, *build.FLAGS, "-S", "--cuda-device-only", "-I", os.path.join(ROOT, "include"), "-o", out, os.path.join(src_dir, src)],
+                       check=True, capture_output=True)
+        txt = open(out).read()
+        found = {}
+        for m in re.finditer(r"- \.agpr_count:\s+(\d+).*?\.group_segment_fixed_size:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?"
+                             r"\.vgpr_count:\s+(\d+).*?\.vgpr_spill_count:\s+(\d+)", txt, re.S):
+            agpr, lds, name, scratch, vgpr, spill = m.groups()
+            body = re.search(r"^%s:[^\n]*\n(.*?)\n\s*s_endpgm" % re.escape(name), txt, re.S | re.M).group(1)
+            found[name] = dict(lds=int(lds), scratch=int(scratch), vgpr=int(vgpr), spill=int(spill), body=body)
+        return found
+
+    def one(ks, prefix):
+        hit = [v for k, v in ks.items() if k.startswith(prefix)]
+        assert len(hit) == 1, (prefix, sorted(ks))
+        return hit[0]
+
+    ks = kernels("nf_mlp.hip")
+    for prefix in ("_Z15k_paper_mlp_fwdILi2E", "_Z20k_paper_mlp_fwd_saveILi2E"):
+        k = one(ks, prefix)
+        assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (prefix, k["spill"], k["scratch"], k["vgpr"])
+        assert k["lds"] == 131072                                        # four wave-private 32 KiB slabs: one workgroup per CU
+        b = k["body"]
+        assert len(re.findall(r"v_mfma_f32_16x16x4_f32", b)) == 5000       # heads, loop bodies and tails of the 11 layers, NT = 2
+        assert "flat_load" not in b and "s_barrier" not in b
+        assert len(re.findall(r"buffer_load_dwordx4", b)) >= 600          # the weight and bias stream
+        assert len(re.findall(r"global_load_dwordx4", b)) == 0            # (the round-2 form: a 64-bit vector address per fragment)
+    ks = kernels("nf_mlp_bwd.hip")
+    k = one(ks, "_Z27k_paper_mlp_bwd_chain_masksILi2E")
+    assert k["spill"] == 0 and k["scratch"] == 0 and k["lds"] == 131072
+    assert len(re.findall(r"buffer_load_dwordx4", k["body"])) >= 200
+    k = one(ks, "_Z13k_dw_gemm_ldsILi0E")
+    assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256     # eight waves = two per SIMD
+    assert len(re.findall(r"buffer_load_dwordx4 .* lds", k["body"])) >= 24 and "global_load_lds" not in k["body"]
