@@ -76,7 +76,10 @@ def build(force: bool = False, verbose: bool = True, _extra=(), _obj="obj", _alw
         newest = max(os.path.getmtime(d) for d in _includes(src) | {os.path.abspath(__file__)})
         if not force and os.path.exists(obj) and os.path.getmtime(obj) > newest:
             continue
-        procs.append((s, subprocess.Popen([cc, *FLAGS, *_extra, "-c", src, "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        # -Rpass-analysis: per-kernel registers / spills / scratch / LDS as compiler remarks, kept beside the object
+        # (lib/obj/<unit>.usage.txt; tests/test_host.py reads them: no kernel of the library may spill)
+        procs.append((s, subprocess.Popen([cc, *FLAGS, *_extra, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj],
+                                          stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         try:
             out, _ = p.communicate(timeout=900)
@@ -85,8 +88,14 @@ def build(force: bool = False, verbose: bool = True, _extra=(), _obj="obj", _alw
             raise RuntimeError(f"hipcc timed out on {s}")
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {s}:\n{out.decode()}")
-        if verbose and out.strip():
-            print(out.decode())
+        text = out.decode()
+        usage = [ln for ln in text.splitlines() if "-Rpass-analysis=kernel-resource-usage" in ln]
+        with open(os.path.join(obj_dir, s.replace(".hip", ".usage.txt")), "w") as f:
+            f.write("\n".join(usage) + "\n")
+        rest = "\n".join(ln for ln in text.splitlines() if "kernel-resource-usage" not in ln and not ln.lstrip().startswith(("|", "^", "In file included from"))
+                         and not ln.strip()[:1].isdigit())
+        if verbose and rest.strip():
+            print(rest)
     cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT]
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
     if r.returncode != 0:

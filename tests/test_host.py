@@ -359,3 +359,29 @@ def test_hot_kernels_keep_their_register_and_instruction_budget(tmp_path):
     k = one(ks, "_Z13k_dw_gemm_ldsILi0E")
     assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256     # eight waves = two per SIMD
     assert len(re.findall(r"buffer_load_dwordx4 .* lds", k["body"])) >= 24 and "global_load_lds" not in k["body"]
+
+
+def test_no_kernel_of_the_library_spills(hip_lib):
+    """Every kernel of libnerface_hip.so, as the compiler reports it when the library is built (-Rpass-analysis=kernel-resource-usage,
+    kept per translation unit in lib/obj/<unit>.usage.txt): no spilled vector registers, no scratch memory, at most 512 VGPRs + AGPRs."""
+    sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
+    import build
+    obj = os.path.join(build.OUT_DIR, "obj")
+    units = [s.replace(".hip", ".usage.txt") for s in build.SOURCES]
+    if not all(os.path.exists(os.path.join(obj, u)) for u in units):
+        build.build(force=True, verbose=False)               # objects cached from before the remarks were kept
+    n = 0
+    for u in units:
+        name = None
+        for ln in open(os.path.join(obj, u)):
+            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill):\s+(\S+)", ln)
+            if not m:
+                continue
+            key, val = m.groups()
+            if key == "Function Name":
+                name, n = val, n + 1
+            elif key in ("ScratchSize [bytes/lane]", "VGPRs Spill"):
+                assert int(val) == 0, (u, name, key, val)
+            elif key in ("VGPRs", "AGPRs"):
+                assert int(val) <= 512, (u, name, key, val)
+    assert n >= 70, n                                           # 79 kernels in round 3
