@@ -178,6 +178,28 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // =================================================================================================
 // forward
 // =================================================================================================
+#ifndef NF_FWD_PREFETCH_IN
+#define NF_FWD_PREFETCH_IN 0     // 1: persistent form only -- the next block's z / ray loads are issued before layers_dir.0 of the current one
+                                 // (the head of a block then does not wait on HBM).  Written at the end of round 3, compiled, NOT yet measured.
+#endif
+struct NfPointIn {
+    float z, ox, oy, oz, dx, dy, dz, dv;
+};
+template <int NT>
+__device__ __forceinline__ void nf_load_point_in(NfPointIn (&in)[NT], int64_t p0, int c, int64_t n_points, int S, const float* __restrict__ ro,
+                                                 const float* __restrict__ rd, const float* __restrict__ rd_view, const float* __restrict__ z) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const int64_t ray = p / S;
+        in[t].z = z[p];
+        in[t].dx = rd[ray * 3 + 0]; in[t].dy = rd[ray * 3 + 1]; in[t].dz = rd[ray * 3 + 2];
+        in[t].ox = ro[ray * 3 + 0]; in[t].oy = ro[ray * 3 + 1]; in[t].oz = ro[ray * 3 + 2];
+        in[t].dv = rd_view[ray * 3 + 2];
+    }
+}
+
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond_, const float* __restrict__ ro,
@@ -190,6 +212,10 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     f32x4* act4 = lds + wave * (16 * NT * 64);
 #if NF_FWD_PERSIST
     // persistent form: one workgroup per CU walks the point blocks with the grid's stride (no workgroup dispatch between blocks)
+#if NF_FWD_PREFETCH_IN
+    NfPointIn in_cur[NT], in_nxt[NT];
+    nf_load_point_in<NT>(in_cur, ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT), c, n_points, S, ro, rd, rd_view, z);   // (clamped: harmless past the end)
+#endif
 #pragma unroll 1
     for (int64_t blk = blockIdx.x;; blk += gridDim.x) {
     const int64_t p0 = (blk * NF_MLP_WAVES + wave) * (16 * NT);
@@ -210,6 +236,16 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     f32x4 dirf[NT][1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
+#if NF_FWD_PERSIST && NF_FWD_PREFETCH_IN
+        const float zz = in_cur[t].z;
+        const float px = nf_add(in_cur[t].ox, nf_mul(in_cur[t].dx, zz));
+        const float py = nf_add(in_cur[t].oy, nf_mul(in_cur[t].dy, zz));
+        const float pz = nf_add(in_cur[t].oz, nf_mul(in_cur[t].dz, zz));
+        nf_encode_point(px, py, pz, g, pe[t]);
+        float s, cs;
+        sincosf(nf_mul(in_cur[t].dv, (float)(1 << g)), &s, &cs);
+        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+#else
         int64_t p = p0 + 16 * t + c;
         if (p >= n_points) p = n_points - 1;
         const int64_t ray = p / S;
@@ -222,6 +258,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
+#endif
     }
 
     f32x4 acc[NT][16];
@@ -280,6 +317,9 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
     nf_tail<NT, 16, 16, 9, 1>(acc, st.wb, bj, st, Wi, OFF_D0 / 4, Ci, B_D0, act4, lane);
+#if NF_FWD_PERSIST && NF_FWD_PREFETCH_IN
+    nf_load_point_in<NT>(in_nxt, ((blk + gridDim.x) * NF_MLP_WAVES + wave) * (16 * NT), c, n_points, S, ro, rd, rd_view, z);   // lands under the four dir layers
+#endif
     // ---- layers_dir.0 : [feat | dir slots] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2) -----------------------
     float sigma_raw[NT];
     {
@@ -368,6 +408,10 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         }
     }
 #if NF_FWD_PERSIST
+#if NF_FWD_PREFETCH_IN
+#pragma unroll
+    for (int t = 0; t < NT; ++t) in_cur[t] = in_nxt[t];
+#endif
     }
 #endif
 }
