@@ -7,6 +7,11 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
+
+#ifndef NF_LCODE_STREAM
+#define NF_LCODE_STREAM 0      // 1: the second family's f32 inference kernel in layer-streamed form (written at the end of round 3, compiled, NOT yet measured / parity-run)
+#endif
 #include "nf_mlp_lcode_layout.h"
 #include "nf_pack.h"
 
@@ -135,6 +140,58 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
     }
     f32x4 acc[NT][16];
+#if NF_LCODE_STREAM
+    // Layer-streamed form (nf_mlp_stream.h; the paper model's k_paper_mlp_fwd is the template).  layers_xyz.2's output feeds fc_alpha AND
+    // fc_feat: fc_alpha's tail stores nothing (NO_ST = 0), so fc_feat reads the same slab again.
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    float sigma_raw[NT];
+    const NfW Wi = nf_w_image(packed, PACKED), Ci = nf_w_image(cond, COND_FLOATS);
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    nf_load_bias<16>(st.bias, Ci, B_L1, lane);                           // layer1: no activation (M:609)
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_X0 / 4, Ci, B_X0, act4, lane);
+    }
+#undef NF_PE_B
+    nf_seg_lds<NT, 16, true, false>(acc, st, Wi, OFF_X0 / 4, 16, act4, lane);       // reads layer1's output as stored
+    nf_pending_b<NT, false>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_X1 / 4, Ci, B_X1, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_X1 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_X2 / 4, Ci, B_X2, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_X2 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 1, 1>(acc, st.wb, bj, st, Wi, OFF_ALPHA / 4, Ci, B_ALPHA, act4, lane);
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_ALPHA / 4, 16, act4, lane);      // fc_alpha(x)
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 1, 0, 16, 1>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);      // feat = relu(fc_feat(x)): the ReLU is the reader's
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 8, 1>(acc, st.wb, bj, st, Wi, OFF_DIR / 4, Ci, B_DIR, act4, lane);
+    {
+        f32x4 wd[16];
+        nf_load_w16<8>(wd, Wi, OFF_DIR / 4 + 16 * 8 * 64, lane);                    // the dir-slot chunk's weights, a layer ahead
+        nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_DIR / 4, 16, act4, lane);    // relu(layers_dir.0([feat | dir]))
+        nf_pending_b<NT, true>(bj, st);
+        nf_chunk<NT, 8, false>(acc, st.wb, bj, st.bias);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_tail<NT, 8, 8, 1, 1>(acc, wd, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    }
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
+#else
 #define NF_LC_FINISH(NO_, RELU_, SEC_, WIDTH_)                                                        \
     do {                                                                                              \
         if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                     \
@@ -167,6 +224,7 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
 #undef NF_LC_FINISH
     nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
     nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
+#endif
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
