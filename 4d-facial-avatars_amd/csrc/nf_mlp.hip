@@ -179,8 +179,8 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // forward
 // =================================================================================================
 #ifndef NF_FWD_PREFETCH_IN
-#define NF_FWD_PREFETCH_IN 0     // 1: persistent form only -- the next block's z / ray loads are issued before layers_dir.0 of the current one
-                                 // (the head of a block then does not wait on HBM).  Written at the end of round 3, compiled, NOT yet measured.
+#define NF_FWD_PREFETCH_IN 0     // 1: persistent form only -- the next block's z / ray loads are issued before layers_dir.0 of the current one.
+                                 // Measured once (profiles/r03_mlp_f32_stream.md section 6): bit-identical, 86.5 vs 86.3 ms -- no gain, off.
 #endif
 struct NfPointIn {
     float z, ox, oy, oz, dx, dy, dz, dv;

@@ -10,7 +10,8 @@
 #include "nf_mlp_stream.h"
 
 #ifndef NF_LCODE_STREAM
-#define NF_LCODE_STREAM 0      // 1: the second family's f32 inference kernel in layer-streamed form (written at the end of round 3, compiled, NOT yet measured / parity-run)
+#define NF_LCODE_STREAM 0      // 1: the second family's f32 inference kernel in layer-streamed form (end of round 3: five parity tests pass on the variant
+                               // build, timing and the full suite pending -- profiles/r03_mlp_f32_stream.md section 6)
 #endif
 #include "nf_mlp_lcode_layout.h"
 #include "nf_pack.h"

@@ -1,5 +1,5 @@
 # First GPU run of the two switches left unmeasured at the end of round 3 (python tools/build_next_variants.py first):
-#  * prefetch: fingerprints must equal the default build's, then the fine-launch time (default: 85.9 ms)
+#  * prefetch: measured once in call 27 (bit-identical, no gain); kept here as the A/B template
 #  * lcode_stream: the second family's parity tests on the variant library, then its eval timing
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/next_ab
