@@ -1,4 +1,5 @@
-// Layer-streamed K loops of the exact-f32 INFERENCE kernels: the layer boundary runs under the MFMAs of the layers it joins.
+// Layer-streamed K loops of the exact-f32 forward kernels (inference: k_paper_mlp_fwd; training: k_paper_mlp_fwd_save, with the copy to
+// `saved`, the ReLU and the mask bits riding in the loops): the layer boundary runs under the MFMAs of the layers it joins.
 //
 // The round-2 kernel finished a layer with one block of non-matrix work per wave: 128 v_accvgpr_read + 256 v_max (the float
 // ReLU is canonicalise + max) + 32 ds_write_b128, then 16 bias loads whose L2 latency nothing covered, 64 v_accvgpr_mov to seed
