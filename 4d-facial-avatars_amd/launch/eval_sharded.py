@@ -4,9 +4,11 @@ test sequence sharded over GPUs (rank r renders frames r, r+W, ...; no collectiv
     torchrun --standalone --nproc-per-node 8 4d-facial-avatars_amd/launch/eval_sharded.py --config cfg.yml --checkpoint ckpt --savedir out
 
 Same CLI flags and checkpoint/dataset schema as the reference (`--config --checkpoint --savedir --save-disparity-image`).
-It renders the straight path (each test frame with its own pose and expression, latent code looked up through
-basedir/index_map.npy when present); the reference's hard-coded `ablate = 'view_dir'` experiment (EV:420-433, Quirk Q7)
-is not reproduced here -- run_one_iter_of_nerf still accepts `ray_directions_ablation` for callers that want it.
+By default it renders the straight path (each test frame with its own pose and expression, latent code looked up through
+basedir/index_map.npy when present).  `--as-shipped` renders what the script AS SHIPPED renders (EV:420-446, Quirk Q7): its
+hard-coded `ablate = 'view_dir'` experiment -- pose and expression frozen to test frame 100, the view directions of the encoding
+taken from pose 240 + i, the latent row idx_map[10, 1], the background re-read from bg/00050.png in float64 (EV:337-343) --
+for the frames i for which pose 240 + i exists (the shipped loop raises IndexError on the first one past them).
 """
 from __future__ import annotations
 
@@ -85,6 +87,10 @@ def _main(argv=None):
                     help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; bf16x3 = split-bf16 kernels, 3x faster, "
                          "within the 1e-4 dB PSNR gate (tests/test_gpu_bf16.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"))
+    ap.add_argument("--as-shipped", action="store_true",
+                    help="render exactly what eval_transformed_rays.py renders as shipped (EV:420-446): ablate = 'view_dir' -- pose and "
+                         "expression of test frame 100, view directions from pose 240 + i, latent row idx_map[10, 1], background from "
+                         "bg/00050.png; frames i with 240 + i < number of test frames")
     args = ap.parse_args(argv)
     rank, world, dev = CM.init_distributed(args.backend)
     nerf.set_mlp_precision(args.precision)
@@ -116,10 +122,26 @@ def _main(argv=None):
     if args.save_disparity_image:
         os.makedirs(os.path.join(args.savedir, "disparity"), exist_ok=True)
     n = poses.shape[0]
+    shipped = None
+    if args.as_shipped:
+        # EV:337-343 `replace_background = True`: the checkpoint's background is dropped for the PNG, read as float64 and divided
+        # by 255 in float64 (the cast to fp32 happens when it is written into the MLP output, T:95-96)
+        from PIL import Image
+        im = Image.open(os.path.join(cfg.dataset.basedir, "bg", "00050.png"))
+        im.thumbnail((H, W))
+        background = (torch.from_numpy(np.array(im).astype(float)).to(dev) / 255).view(-1, 3)
+        if idx_map is None:
+            raise SystemExit("--as-shipped: the shipped script needs basedir/index_map.npy (EV:329)")
+        if n <= 240:
+            raise SystemExit(f"--as-shipped: the shipped loop reads test poses 100 and 240 + i (EV:424-433); this sequence has {n} frames")
+        row = int(idx_map[10, 1])                                         # EV:444 "Fixes latent code - USE THIS if not ablating!"
+        shipped = {"pose": poses[100, :3, :4].float().to(dev), "expr": expressions[100].float().to(dev),
+                   "latent": latent_codes[row].to(dev)}
+        n = n - 240                                                       # frames whose pose 240 + i exists
     mine = D.shard_frames(n, rank, world)
     times = []
     writer = PngWriter()
-    if args.save_normals:
+    if args.save_normals or args.as_shipped:
         os.makedirs(os.path.join(args.savedir, "normals"), exist_ok=True)
     if args.save_error_image:
         os.makedirs(os.path.join(args.savedir, "error"), exist_ok=True)
@@ -130,17 +152,26 @@ def _main(argv=None):
     for i in mine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-        row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
-        latent = latent_codes[min(max(row, 0), latent_codes.shape[0] - 1)]
-        with torch.no_grad():
-            ro, rd = nerf.get_ray_bundle(H, W, intrinsics, poses[i, :3, :4].to(dev))
-            out = nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
-                                            encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
-                                            expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
+        if shipped is not None:
+            with torch.no_grad():
+                _, rd_abl = nerf.get_ray_bundle(H, W, intrinsics, poses[240 + i, :3, :4].float().to(dev))     # EV:433
+                ro, rd = nerf.get_ray_bundle(H, W, intrinsics, shipped["pose"])
+                out = nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
+                                                encode_position_fn=enc_xyz, encode_direction_fn=enc_dir, expressions=shipped["expr"],
+                                                background_prior=background, latent_code=shipped["latent"],
+                                                ray_directions_ablation=rd_abl)
+        else:
+            row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
+            latent = latent_codes[min(max(row, 0), latent_codes.shape[0] - 1)]
+            with torch.no_grad():
+                ro, rd = nerf.get_ray_bundle(H, W, intrinsics, poses[i, :3, :4].to(dev))
+                out = nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
+                                                encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                                expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
         rgb = out[3] if out[3] is not None else out[0]
         # clamp / quantise (and the normal map) on the device: only uint8 crosses PCIe
-        rgb_u8, normals_u8 = ops.eval_postprocess(rgb[..., :3], out[4] if args.save_normals else None, out[6], intrinsics,
-                                                  want_normals=args.save_normals and out[4] is not None)
+        want_n = (args.save_normals or shipped is not None) and out[4] is not None            # EV:469-471 always writes normals/
+        rgb_u8, normals_u8 = ops.eval_postprocess(rgb[..., :3], out[4] if want_n else None, out[6], intrinsics, want_normals=want_n)
         writer.submit(rgb_u8, os.path.join(args.savedir, f"{i:04d}.png"))
         if normals_u8 is not None:
             writer.submit(normals_u8, os.path.join(args.savedir, "normals", f"{i:04d}.png"))

@@ -142,7 +142,9 @@ def main(argv=None):
         logs_now = i % cfg.experiment.print_every == 0 or i == cfg.experiment.train_iters - 1
         saves_now = i % cfg.experiment.save_every == 0 or i == cfg.experiment.train_iters - 1
         if f16 and (logs_now or saves_now):
-            nerf.ops.check_f16_range(model_c, model_f)         # every rank: raises if any step since the last poll overflowed fp16
+            # every rank raises TOGETHER (flag MAX-reduced) if any rank's step since the last poll overflowed fp16 -- before the
+            # checkpoint below is written
+            nerf.ops.check_f16_range(model_c, model_f, sync_ranks=True)
         if rank == 0:
             # TR:415-424, device-side: the scalars of every iteration, read back together when the iteration prints
             log.add_scalar("train/code_loss", code_loss.detach(), i)

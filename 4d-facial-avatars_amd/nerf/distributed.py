@@ -68,6 +68,32 @@ class GradientAllReducer:
         self.mask = None               # agreed has-gradient pattern (list of bool), fixed after the first reduce()
         self._buf = None
         self._views = None
+        self._timing = None            # enable_timing(): (start, end) event pairs / host seconds of the flat all-reduce
+        self.calls = 0
+
+    # ---- evidence for the N > 1 path (bench.py --gpus N, launch/train_sharded.py): how many ranks the communicator saw, how many
+    # bytes one step moves, what the collective cost.  Off by default: no events, no host work.
+    def enable_timing(self, keep: int = 512) -> None:
+        self._timing = {"keep": int(keep), "pairs": [], "host_s": []}
+
+    def stats(self) -> dict:
+        """{"ranks_seen", "bytes_allreduced", "allreduce_us" (median over the recorded steps, first step excluded), "calls"}.
+        Synchronises the device (reads the events): call it outside the timed region."""
+        import statistics
+        _, world = world_info()
+        ranks = dist.get_world_size(self.group) if dist.is_available() and dist.is_initialized() else 1
+        us = []
+        if self._timing is not None:
+            if self._timing["pairs"]:
+                torch.cuda.synchronize()
+                us = [1e3 * a.elapsed_time(b) for a, b in self._timing["pairs"]]
+            else:
+                us = [1e6 * t for t in self._timing["host_s"]]
+        us = us[1:] if len(us) > 1 else us                                  # the first call negotiates / warms the communicator
+        return {"ranks_seen": int(ranks), "world_size": int(world), "calls": int(self.calls),
+                "bytes_allreduced": int(self._buf.numel() * self._buf.element_size()) if self._buf is not None else 0,
+                "allreduce_us": float(statistics.median(us)) if us else None, "allreduce_samples": len(us),
+                "backend": dist.get_backend(self.group) if dist.is_available() and dist.is_initialized() else None}
 
     def reset(self) -> None:
         """Forget the agreed gradient pattern (after (un)freezing parameters).  Collective: call on every rank."""
@@ -128,7 +154,23 @@ class GradientAllReducer:
         with torch.no_grad():
             run_g, run_v = self._runs(grads, views)
             torch._foreach_copy_(run_v, run_g)
-            dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+            tm = self._timing
+            if tm is None:
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+            elif self._buf.is_cuda:                                       # HIP events on the launch stream around the collective
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+                e1.record()
+                tm["pairs"].append((e0, e1))
+                del tm["pairs"][:-tm["keep"]]
+            else:
+                import time
+                t0 = time.perf_counter()
+                dist.all_reduce(self._buf, op=dist.ReduceOp.SUM, group=self.group)
+                tm["host_s"].append(time.perf_counter() - t0)
+                del tm["host_s"][:-tm["keep"]]
+            self.calls += 1
             self._buf.mul_(1.0 / world)
             torch._foreach_copy_(run_g, run_v)
 

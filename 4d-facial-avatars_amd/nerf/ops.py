@@ -364,12 +364,21 @@ def f16_preflight(model, ro, rd, z, rd_view, expr, latent, near, far, max_rays: 
     return float(saved[64 * n:2240 * n].abs().max().item())          # sections S_H0 .. S_D2 (csrc/nf_mlp_layout.h): every hidden layer output
 
 
-def check_f16_range(*models) -> None:
+def check_f16_range(*models, sync_ranks: bool = False) -> None:
     """Raise if the split-fp16 kernels of any of `models` flagged a non-finite output since their weights were last packed
-    (one 4-byte read-back per model; called once per rendered frame, never inside a ray chunk)."""
+    (one 4-byte read-back per model; called once per rendered frame, never inside a ray chunk).
+    sync_ranks (data-parallel training): the flag is MAX-reduced over the process group first, so that every rank raises on the
+    same iteration -- a rank that raised alone would leave the others waiting in the next gradient all-reduce."""
     flags = [m.hip_weights().f16_range_flag() for m in models if m is not None and hasattr(m, "hip_weights")]
     flags = [f for f in flags if f is not None]
-    if flags and int(torch.stack(flags).sum().item()) != 0:
+    if not flags:
+        return
+    total = torch.stack(flags).sum().to(torch.int32).reshape(1)
+    if sync_ranks:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.MAX)
+    if int(total.item()) != 0:
         raise RuntimeError('nerf.set_mlp_precision("f16x3"): an activation left the fp16 range (|x| >= 4094) and a density output is not '
                            'finite -- render this model with "f32" or "bf16x3"')
 

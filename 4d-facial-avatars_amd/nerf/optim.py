@@ -26,6 +26,15 @@ class Adam(torch.optim.Optimizer):
             raise ValueError("invalid Adam hyper-parameters")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=0, amsgrad=False, maximize=False))
 
+    def __setstate__(self, state):
+        """torch.optim.Adam.__setstate__'s normalisation: checkpoints written by the reference's torch versions (<= 1.11) hold
+        `step` as a Python int, fused / capturable ones as a device tensor; here it is always a 0-d float32 CPU tensor."""
+        super().__setstate__(state)
+        for st in self.state.values():
+            if "step" in st:
+                s_ = st["step"]
+                st["step"] = torch.tensor(float(s_.item() if torch.is_tensor(s_) else s_), dtype=torch.float32)
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = None
@@ -36,9 +45,9 @@ class Adam(torch.optim.Optimizer):
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise NotImplementedError("nerf.optim.Adam: weight_decay / amsgrad / maximize are not part of the trainer's configuration")
-            by_step = {}                                   # tensors that have taken the same number of steps go into one launch
-            for p in group["params"]:
-                if p.grad is None:
+            todo = []
+            for p in group["params"]:                      # validate EVERYTHING first: a refused tensor must not leave others half-stepped
+                if p.grad is None or p.numel() == 0:       # (zero-element parameters: nothing to update, as in torch.optim.Adam)
                     continue
                 if p.grad.is_sparse:
                     raise RuntimeError("nerf.optim.Adam does not support sparse gradients")
@@ -47,13 +56,17 @@ class Adam(torch.optim.Optimizer):
                     raise RuntimeError("nerf.optim.Adam (MI355X build): parameters must be contiguous float32 tensors on a ROCm device")
                 if g.dtype != torch.float32 or g.device != p.device:
                     raise RuntimeError("nerf.optim.Adam: gradients must be float32 on the parameter's device")
-                if not g.is_contiguous():
-                    g = g.contiguous()
+                todo.append((p, g if g.is_contiguous() else g.contiguous()))
+            by_step = {}                                   # tensors that have taken the same number of steps go into one launch
+            for p, g in todo:
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                elif not torch.is_tensor(st["step"]) or st["step"].is_cuda:      # int (old checkpoints) / device tensor: normalise once
+                    s_ = st["step"]
+                    st["step"] = torch.tensor(float(s_.item() if torch.is_tensor(s_) else s_), dtype=torch.float32)
                 st["step"] += 1
                 by_step.setdefault((int(st["step"].item()), p.device), []).append((p, g, st["exp_avg"], st["exp_avg_sq"]))
             beta1, beta2 = group["betas"]
@@ -64,4 +77,8 @@ class Adam(torch.optim.Optimizer):
                 with torch.cuda.device(dev):
                     H.check(lib.nf_adam_step(arr(0), arr(1), arr(2), arr(3), numel, n, float(group["lr"]), float(beta1), float(beta2),
                                              float(group["eps"]), step, H.stream_ptr(dev)), "nf_adam_step")
+                # the kernel wrote through raw pointers: tell autograd (in-place checks, and every cache keyed on `_version`:
+                # the split-fp16 range probe of nerf/models.py) that these tensors changed
+                for it in items:
+                    torch.autograd.graph.increment_version(it[0])
         return loss

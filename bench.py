@@ -102,32 +102,91 @@ def options(nerf, chunk=CHUNK):
                              dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
 
 
+def _reference_cpu_run(n_rays, c, cores):
+    """The reference's OWN CPU path on this box's host cores: the unmodified `get_ray_bundle` (H:68-123) for the whole 512x512
+    frame plus the unmodified `run_one_iter_of_nerf` (T:165-290) on `n_rays` rays of it, imported from the live tree or from
+    oracle/_ref/nerface_ref.zip (oracle/make_ref.py packs the untouched files; the archive travels with the push).  Returns
+    (outputs, seconds of run_one_iter_of_nerf on the sample, seconds of the full-frame get_ray_bundle, threads, kind string)."""
+    from oracle import make_golden as MG
+    from oracle import nerface_oracle as O
+    from oracle import ref_import as RI
+    ref = RI.import_reference()
+    warm = dict(c)
+    warm.update(ro=c["ro"][:256], rd=c["rd"][:256], bg=c["bg"][:256])
+    best, best_t = cores, None
+    with torch.no_grad():
+        # torch-CPU GEMMs of this size do not scale to every hardware thread of a big host: calibrate the thread count on a
+        # 256-ray slice first and time the sample with the best one (reported as `cores`)
+        for nt in sorted({min(cores, k) for k in (16, 32, 64, cores)}):
+            torch.set_num_threads(nt)
+            MG.run_reference(ref, warm)
+            t0 = time.perf_counter()
+            MG.run_reference(ref, warm)
+            t = time.perf_counter() - t0
+            if best_t is None or t < best_t:
+                best, best_t = nt, t
+        torch.set_num_threads(best)
+        pose = O.frame_pose(c["frame"])[:3, :4]
+        ref.get_ray_bundle(H, W, INTRINSICS, pose)
+        t0 = time.perf_counter()
+        ref.get_ray_bundle(H, W, INTRINSICS, pose)
+        t_bundle = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out, _ = MG.run_reference(ref, c)
+        dt = time.perf_counter() - t0
+    return out, dt, t_bundle, best, RI.reference_kind()
+
+
 def cpu_baseline(n_rays=12288):
-    """Oracle (CPU port of the reference path) on a bounded sample: n_rays rays of one 512^2 frame, 64+128."""
+    """The CPU baseline beside the headline, on a bounded sample: n_rays rays of one 512^2 frame, 64+128 samples.
+    kind "reference": the UNMODIFIED reference code timed on this box (see _reference_cpu_run); the oracle port is timed on a
+    slice of the same rays beside it (`port`).  kind "port" (labelled fallback): only when neither /root/reference nor
+    oracle/_ref/ is present."""
     from oracle import cases as C
     from oracle import nerface_oracle as O
+    from oracle import ref_import as RI
     cores = os.cpu_count() or 1
     c = C.build_case("eval_det_64_128")
     ro, rd, bg, _, _ = C.ray_subset(H, W, 3, n_rays, seed=5)
     c.update(ro=ro, rd=rd, bg=bg)
     warm = dict(c)
     warm.update(ro=ro[:256], rd=rd[:256], bg=bg[:256])
-    # torch-CPU GEMMs of this size do not scale to every hardware thread of a big host: calibrate the thread count on a
-    # 256-ray slice first and time the sample with the best one (reported as `cores`)
-    best, best_t = cores, None
-    with torch.no_grad():
-        for nt in sorted({min(cores, k) for k in (16, 32, 64, cores)}):
-            torch.set_num_threads(nt)
-            C.run_oracle(warm)
+    kind, ref_detail, port_detail = "port", None, None
+    if RI.reference_importable():
+        try:
+            ref, dt, t_bundle, best, how = _reference_cpu_run(n_rays, c, cores)
+            kind = "reference"
+            t_total = dt + t_bundle * n_rays / float(H * W)                # the frame's ray bundle, charged per ray
+            ref_detail = {"run_one_iter_of_nerf_s": dt, "get_ray_bundle_full_frame_s": t_bundle, "imported_from": how}
+            # the oracle port on a slice of the same rays, same threads: how close the restatement's speed is to the real thing
+            n_port = min(n_rays, 2048)
+            cp = dict(c)
+            cp.update(ro=ro[:n_port], rd=rd[:n_port], bg=bg[:n_port])
+            with torch.no_grad():
+                C.run_oracle(warm)
+                t0 = time.perf_counter()
+                got = C.run_oracle(cp)
+                dtp = time.perf_counter() - t0
+            port_detail = {"value": n_port / dtp, "unit": "rays/s", "rays": n_port,
+                           "bit_identical_to_reference_on_slice": bool(all(torch.equal(a, b[:n_port]) for a, b in zip(got, ref)))}
+        except Exception as e:                                              # never lose the baseline to the stronger leg
+            kind, ref_detail = "port", {"reference_error": repr(e)}
+    if kind == "port":
+        best, best_t = cores, None
+        with torch.no_grad():
+            for nt in sorted({min(cores, k) for k in (16, 32, 64, cores)}):
+                torch.set_num_threads(nt)
+                C.run_oracle(warm)
+                t0 = time.perf_counter()
+                C.run_oracle(warm)
+                t = time.perf_counter() - t0
+                if best_t is None or t < best_t:
+                    best, best_t = nt, t
+            torch.set_num_threads(best)
             t0 = time.perf_counter()
-            C.run_oracle(warm)
-            t = time.perf_counter() - t0
-            if best_t is None or t < best_t:
-                best, best_t = nt, t
-        torch.set_num_threads(best)
-        t0 = time.perf_counter()
-        ref = C.run_oracle(c)
-        dt = time.perf_counter() - t0
+            ref = C.run_oracle(c)
+            dt = time.perf_counter() - t0
+        t_total = dt
     # parity of the product on exactly this sample (same rays, weights, conditioning; deterministic sampling): the
     # north-star gate |PSNR(ours, target) - PSNR(reference algorithm, target)| <= 1e-4 dB, in both precisions
     parity = {}
@@ -163,21 +222,13 @@ def cpu_baseline(n_rays=12288):
         parity["mlp_output_scale"] = want.abs().amax(dim=(0, 1)).tolist()
     except Exception as e:                                    # the baseline number must not depend on this extra
         parity = {"error": repr(e)}
-    ratio = None
-    rpath = os.path.join(ROOT, "profiles", "r02_port_vs_reference_cpu.json")
-    if os.path.exists(rpath):
-        try:
-            ratio = json.load(open(rpath))
-        except Exception:
-            ratio = None
-    if isinstance(ratio, dict):
-        ratio = {"replayed": True, "measured_in": "the build container (the unmodified reference cannot travel to the GPU box), once, round 2",
-                 "file": "profiles/r02_port_vs_reference_cpu.json", **ratio}
-    return {"value": n_rays / dt, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
-            "host_cores": os.cpu_count(), "kind": "port",
-            "cores_note": "`cores` = torch CPU threads the calibration below picked for the timed sample; `host_cores` = os.cpu_count() of this box",
-            "reference_ratio": ratio,
-            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, fp32 torch-CPU oracle, {dt:.1f} s",
+    what = ("UNMODIFIED reference get_ray_bundle + run_one_iter_of_nerf (torch-CPU fp32)" if kind == "reference"
+            else "fp32 torch-CPU oracle (port of the reference path; oracle/_ref absent on this box)")
+    return {"value": n_rays / t_total, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
+            "host_cores": os.cpu_count(), "kind": kind,
+            "cores_note": "`cores` = torch CPU threads the calibration picked for the timed sample; `host_cores` = os.cpu_count() of this box",
+            "reference": ref_detail, "port": port_detail,
+            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, {what}, {t_total:.1f} s",
             "parity_on_sample": parity}
 
 
@@ -276,9 +327,10 @@ def train_roofline(args, model, dev, n_rays):
             ach = TRAIN_FLOP_PER_POINT[k] * n_big / t / 1e12
             obj = {"bound": "mfma", "achieved": ach, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F32_MFMA_TFLOPS,
                    "algorithmic_flops_per_point": TRAIN_FLOP_PER_POINT[k]}
-            if k == 0:
+            if k == 0:                                                   # frac = the executed (physical) fraction, like the headline's
                 obj["executed_tflops"] = EXEC_FLOP_PER_POINT_F32 * n_big / t / 1e12
                 obj["frac_executed"] = obj["executed_tflops"] / PEAK_F32_MFMA_TFLOPS
+                obj["frac_algorithmic"], obj["frac"] = obj["frac"], obj["frac_executed"]
         else:
             ach = TRAIN_BYTES_PER_POINT[k] * n_big / t / 1e9
             obj = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
@@ -316,6 +368,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     D.broadcast_parameters(params)
     optim = nerf.optim.Adam(params, lr=5e-4)                   # torch.optim.Adam's update rule (TR:193-199) for all 54 tensors in one launch
     reducer = D.GradientAllReducer(params)
+    reducer.enable_timing()                                               # HIP events around the flat all-reduce (no-op at world 1 without a group)
     g = torch.Generator().manual_seed(7)
     background = torch.rand((H, W, 3), generator=g).to(dev)
     target = torch.rand((H, W, 3), generator=g).to(dev)
@@ -366,10 +419,12 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
         dt = float(t.item())
     assert bool(torch.isfinite(loss))
     roofline = train_roofline(args, model_f, dev, n_rays) if rank == 0 else None
+    allreduce = reducer.stats()          # ranks the communicator saw, bytes per step, median HIP-event time of the collective
     result = None
     if rank == 0:
         result = {
-            "roofline": roofline,
+            "roofline": roofline, "allreduce": allreduce, "ranks_seen": allreduce["ranks_seen"],
+            "allreduce_us": allreduce["allreduce_us"], "bytes_allreduced": allreduce["bytes_allreduced"],
             "metric": "training rays/sec (2048 rays/iter, 64+64 samples, fwd+bwd+Adam)", "value": world * args.steps * n_rays / dt,
             "unit": "rays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -381,6 +436,10 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
                        "mlp_precision": args.precision, "family": args.family}}
         if emit:
             result["config"]["device"] = device_info(dev)
+            result["summary"] = {"value_rays_s": result["value"], "ms_per_step": result["ms_per_step"], "n_gpus": world,
+                                 "ranks_seen": allreduce["ranks_seen"], "allreduce_us": allreduce["allreduce_us"],
+                                 "bytes_allreduced": allreduce["bytes_allreduced"], "mlp_precision": args.precision,
+                                 "hbm_fill_gbs": result["config"]["device"].get("hbm_fill_gbs")}
             print(json.dumps(result), flush=True)
     if dist is not None:
         dist.barrier()
@@ -555,45 +614,110 @@ def device_info(dev):
             "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
 
 
+def _pmc_guard():
+    """rocprofv3 path, or (None, reason).  Never nest profilers: a PMC pass started from a process that is itself being traced
+    combines counter collection with tracing -- the combination this pool's nodes do not survive."""
+    import shutil
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None, {"error": "rocprofv3 not found"}
+    under = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER"))]
+    if under or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
+        return None, {"skipped": "bench.py is running under a profiler (" + ", ".join(sorted(under)[:4]) + "); PMC passes not nested"}
+    return prof, None
+
+
+def pmc_pass_rows(prof, tmp, counter, script, argv, timeout):
+    """One `rocprofv3 --kernel-trace --pmc <counter>` pass over tools/<script> <argv>: [(kernel_name, grid_x, value, duration_ns
+    or None)] per dispatch, or (None, detail).  The dispatch duration comes from the same pass (the counters view's own
+    start / end stamps when it has them, else the kernel trace joined on the dispatch id)."""
+    import sqlite3
+    out = os.path.join(tmp, counter)
+    env = dict(os.environ, TMPDIR=tmp)
+    env.pop("RANK", None)
+    env.pop("WORLD_SIZE", None)
+    cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script), *argv]
+    r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
+    dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+    if r.returncode != 0 or not dbs:
+        return None, {"error": f"rocprofv3 pass {counter} failed (rc {r.returncode})", "tail": r.stdout.decode()[-400:]}
+    con = sqlite3.connect(dbs[0])
+    cols = [c[1] for c in con.execute("pragma table_info(counters_collection)").fetchall()]
+    if "start" in cols and "end" in cols:
+        rows = con.execute('select kernel_name, grid_size_x, value, "end" - "start" from counters_collection where counter_name = ?',
+                           (counter,)).fetchall()
+    elif "dispatch_id" in cols:
+        try:
+            kcols = [c[1] for c in con.execute("pragma table_info(kernels)").fetchall()]
+            key = "dispatch_id" if "dispatch_id" in kcols else "id"
+            rows = con.execute(f"select c.kernel_name, c.grid_size_x, c.value, k.duration from counters_collection c left join kernels k "
+                               f"on k.{key} = c.dispatch_id where c.counter_name = ?", (counter,)).fetchall()
+        except Exception:
+            rows = [(n, g, v, None) for n, g, v in con.execute(
+                "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()]
+    else:
+        rows = [(n, g, v, None) for n, g, v in con.execute(
+            "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()]
+    return rows, None
+
+
 def pmc_kernel_bytes(script, argv, kernels, timeout=240):
     """HBM bytes per launch of the named kernels, measured by THIS command: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
     cannot share a pass on gfx950, MI355X_MICROARCH.md) over tools/<script> <argv>.  Per kernel (substring match, its largest grid):
     {"fetch_bytes", "write_bytes"}, the counters' KiB x 1024, raw.  Returns (dict or None, detail)."""
     import shutil
-    import sqlite3
     import tempfile
-    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
-        return None, {"error": "rocprofv3 not found"}
-    # never nest profilers: a PMC pass started from a process that is itself being traced combines counter collection with
-    # tracing -- the combination this pool's nodes do not survive.  Under any rocprofiler the PMC passes are skipped.
-    under = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER"))]
-    if under or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
-        return None, {"skipped": "bench.py is running under a profiler (" + ", ".join(sorted(under)[:4]) + "); PMC passes not nested"}
+    prof, why = _pmc_guard()
+    if prof is None:
+        return None, why
     got = {k: {} for k in kernels}
     tmp = tempfile.mkdtemp(prefix="nf_pmc_")
     try:
         for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            out = os.path.join(tmp, counter)
-            env = dict(os.environ, TMPDIR=tmp)
-            env.pop("RANK", None)
-            env.pop("WORLD_SIZE", None)
-            cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script), *argv]
-            r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
-            dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
-            if r.returncode != 0 or not dbs:
-                return None, {"error": f"rocprofv3 pass {counter} failed (rc {r.returncode})", "tail": r.stdout.decode()[-400:]}
-            rows = sqlite3.connect(dbs[0]).execute(
-                "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()
+            rows, err = pmc_pass_rows(prof, tmp, counter, script, argv, timeout)
+            if rows is None:
+                return None, err
             for kernel in kernels:
-                hits = [(gx, v) for n, gx, v in rows if kernel in n]
+                hits = [(gx, v) for n, gx, v, _ in rows if kernel in n]
                 big = max((gx for gx, _ in hits), default=None)           # the launch of interest is the kernel's largest grid
                 vals = [v for gx, v in hits if gx == big]
                 if not vals:
-                    return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _ in rows})[:8]}
+                    return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _, _ in rows})[:8]}
                 got[kernel]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = sum(vals) / len(vals) * 1024.0
         return got, {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) run by bench.py on tools/{script} "
                                + " ".join(argv) + " in this run"}
+    except Exception as e:
+        return None, {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def pmc_sustained_clock(precision="f32", timeout=240):
+    """The engine clock the headline kernel actually held: GRBM_GUI_ACTIVE (busy cycles of the graphics engine) of its fine-pass launch
+    divided by the duration of the same dispatch, from one rocprofv3 PMC pass over tools/pmc_one_launch.py.  rocprofv3 sums the
+    counter over the 8 XCDs of the device (profiles/r01_mlp_kernels_pmc.md: 18.7e9 'cycles' per second), so a quotient above 6 GHz
+    is divided by the XCD count.  Returns (MHz or None, detail)."""
+    import shutil
+    import tempfile
+    prof, why = _pmc_guard()
+    if prof is None:
+        return None, why
+    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
+    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
+    try:
+        rows, err = pmc_pass_rows(prof, tmp, "GRBM_GUI_ACTIVE", "pmc_one_launch.py", [precision], timeout)
+        if rows is None:
+            return None, err
+        hits = [(v, d) for n, _, v, d in rows if kernel in n and d]
+        if not hits:
+            return None, {"error": "no dispatch of the kernel with a duration in the GRBM_GUI_ACTIVE pass",
+                          "kernels": sorted({n[:60] for n, _, _, _ in rows})[:8]}
+        per = sorted(v / (d * 1e-9) for v, d in hits)
+        hz = per[len(per) // 2]
+        div = 8 if hz > 6e9 else 1
+        return hz / div / 1e6, {"source": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE run by bench.py on tools/pmc_one_launch.py " + precision,
+                                "kernel": kernel, "dispatches": len(hits), "busy_cycles_raw_median": sorted(v for v, _ in hits)[len(hits) // 2],
+                                "dispatch_ms_under_pmc_median": sorted(d for _, d in hits)[len(hits) // 2] / 1e6, "xcd_sum_divisor": div}
     except Exception as e:
         return None, {"error": repr(e)}
     finally:
@@ -770,7 +894,8 @@ def main():
             r = bench_train(args, nerf, mc_t, mf_t, dev, rank, world, dist, emit=False)
             if r is not None:
                 train[prec] = {"value": r["value"], "unit": r["unit"], "ms_per_iter": r["ms_per_step"], "iters": r["steps"],
-                               "warmup": r["warmup"], "roofline": r["roofline"]}
+                               "warmup": r["warmup"], "roofline": r["roofline"], "allreduce": r["allreduce"]}
+                train["allreduce"] = r["allreduce"]                       # (the same collective in every arithmetic: fp32 gradients)
         args.steps, args.warmup, args.precision = keep_steps, keep_warm, keep_prec
         nerf.set_mlp_precision(args.precision)
         if rank == 0:
@@ -808,17 +933,21 @@ def main():
         ms = {"f32": timed(lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
               "bf16x3": timed(lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z)),
               "f16x3": timed(lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z))}
+        exe_f32 = float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12
         objs = {"f32": {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2> (65536 rays x 192 samples per launch)",
                         "achieved": flops / (ms["f32"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                        "frac": flops / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "avg_launch_ms": ms["f32"],
+                        "frac": exe_f32 / PEAK_F32_MFMA_TFLOPS,
+                        "frac_algorithmic": flops / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "avg_launch_ms": ms["f32"],
                         "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes, "traffic": None,
-                        "executed_tflops": float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12,
-                        "frac_executed": float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                        "executed_tflops": exe_f32, "frac_executed": exe_f32 / PEAK_F32_MFMA_TFLOPS,
+                        "frac_at_sustained_clock": None, "sustained_clock_mhz": None,
                         "note": "achieved counts the ALGORITHMIC FLOPs of the reference MLP (1,100,032 per point); the kernel folds the per-frame "
-                                "constant input columns (expression, latent code, PE(near), PE(far)) into bias vectors and issues 999,936 "
-                                "MFMA FLOPs per point: executed_tflops / frac_executed (= the matrix pipe's busy fraction at the nominal clock; "
-                                "PMC of the round-2 kernel: profiles/r03_mlp_f32_pmc.md, the layer-streamed kernel: profiles/r03_mlp_f32_stream.md).  "
-                                "frac above 1 is not an error: the folded 9 % of the algorithmic FLOPs cost no matrix cycles"}}
+                                "constant input columns (expression, latent, PE(near), PE(far)) into bias vectors and issues 999,936 MFMA FLOPs per "
+                                "point.  frac = executed_tflops / peak: the physical busy fraction of the fp32 matrix pipe at the NOMINAL 2.4 GHz clock "
+                                "(<= 1); frac_algorithmic = achieved / peak may exceed 1 (the folded 9 % cost no matrix cycles); "
+                                "frac_at_sustained_clock prices the executed FLOPs against 256 CUs x 256 FLOP/clk x the clock this kernel actually "
+                                "held (GRBM_GUI_ACTIVE / dispatch time, a PMC pass of this run)"}}
         for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
             exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms[prec] * 1e-3) / 1e12
@@ -834,6 +963,12 @@ def main():
         if world == 1 and not args.no_extras:
             for prec in ("f32", "f16x3", "bf16x3"):
                 objs[prec]["traffic"], objs[prec]["traffic_detail"] = pmc_traffic(prec)
+            mhz, clk_detail = pmc_sustained_clock("f32")
+            objs["f32"]["sustained_clock_mhz"], objs["f32"]["sustained_clock_detail"] = mhz, clk_detail
+            if mhz:
+                peak_at = line["config"]["device"]["compute_units"] * 256 * mhz * 1e6 / 1e12
+                objs["f32"]["peak_at_sustained_clock_tflops"] = peak_at
+                objs["f32"]["frac_at_sustained_clock"] = objs["f32"]["executed_tflops"] / peak_at
         line["roofline"] = objs[args.precision]
         for other in others:
             line.setdefault(key_of[other], {})["roofline"] = objs[other]
@@ -857,10 +992,54 @@ def main():
             for other in others:
                 if isinstance(par, dict) and other in par and key_of[other] in line:
                     line[key_of[other]]["parity_on_sample"] = par[other]
+        line["ranks_seen"] = int(dist.get_world_size()) if dist is not None else 1
+        line["summary"] = summary_of(line)                                # LAST key: the driver keeps only the tail of the line
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def summary_of(line):
+    """Flat scalars at the very end of the JSON line (the driver's record keeps a few KB of tail): everything a reader needs to check
+    the claims of DESIGN.md against the driver's own run."""
+    def g(*path, default=None):
+        o = line
+        for k in path:
+            if not isinstance(o, dict) or k not in o:
+                return default
+            o = o[k]
+        return o
+    s = {"value_rays_s": line.get("value"), "ms_per_step": line.get("ms_per_step"), "n_gpus": line.get("n_gpus"),
+         "ranks_seen": line.get("ranks_seen"), "dtype": line.get("dtype"),
+         "roofline_frac": g("roofline", "frac"), "roofline_frac_algorithmic": g("roofline", "frac_algorithmic"),
+         "roofline_frac_at_sustained_clock": g("roofline", "frac_at_sustained_clock"),
+         "roofline_avg_launch_ms": g("roofline", "avg_launch_ms"), "roofline_traffic_bytes": g("roofline", "traffic"),
+         "sustained_clock_mhz": g("roofline", "sustained_clock_mhz"),
+         "split_f16_rays_s": g("split_f16", "value"), "split_bf16_rays_s": g("split_bf16", "value"),
+         "split_f16_fine_launch_ms": g("split_f16", "roofline", "avg_launch_ms"),
+         "split_bf16_fine_launch_ms": g("split_bf16", "roofline", "avg_launch_ms"),
+         "split_f16_frac_executed": g("split_f16", "roofline", "frac_executed"),
+         "split_bf16_frac_executed": g("split_bf16", "roofline", "frac_executed")}
+    for prec in ("f32", "f16x3", "bf16x3"):
+        s[f"train_ms_per_iter_{prec}"] = g("train", prec, "ms_per_iter")
+        ks = g("train", prec, "roofline", "kernels", default=[]) or []
+        for tag, k in zip(("fwd_save", "chain", "dw"), ks):
+            s[f"train_{prec}_{tag}_ms"] = k.get("avg_launch_ms")
+            s[f"train_{prec}_{tag}_frac"] = k.get("frac")
+    ar = g("train", "allreduce") or {}
+    s.update({"train_allreduce_us": ar.get("allreduce_us"), "train_bytes_allreduced": ar.get("bytes_allreduced"),
+              "train_ranks_seen": ar.get("ranks_seen"),
+              "hbm_fill_gbs": g("config", "device", "hbm_fill_gbs"), "hbm_copy_gbs": g("config", "device", "hbm_copy_gbs"),
+              "engine_clock_mhz": g("config", "device", "engine_clock_mhz"),
+              "eager_rocm_rays_s": g("eager_rocm", "value"), "product_over_eager": g("eager_rocm", "product_over_eager"),
+              "cpu_baseline_rays_s": g("cpu_baseline", "value"), "cpu_baseline_kind": g("cpu_baseline", "kind"),
+              "cpu_baseline_cores": g("cpu_baseline", "cores"), "host_cores": g("cpu_baseline", "host_cores"),
+              "abs_dpsnr_db_f32": g("cpu_baseline", "parity_on_sample", "f32", "abs_dpsnr_db_fine"),
+              "abs_dpsnr_db_f16x3": g("cpu_baseline", "parity_on_sample", "f16x3", "abs_dpsnr_db_fine"),
+              "abs_dpsnr_db_bf16x3": g("cpu_baseline", "parity_on_sample", "bf16x3", "abs_dpsnr_db_fine"),
+              "tiny_rays_s": g("tiny", "value")})
+    return s
 
 
 if __name__ == "__main__":

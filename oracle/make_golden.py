@@ -130,6 +130,26 @@ def make_eval_post():
     print("eval_post fixture written (oracle restatement == reference, bit exact)")
 
 
+def make_eval_as_shipped(n_frames=2):
+    """The UNMODIFIED eval script run as shipped (EV:201-498: `ablate = 'view_dir'`, pose / expression frozen to test frame 100, view
+    directions from pose 240 + i, latent row idx_map[10, 1], background re-read from bg/00050.png) on the CPU of the build container
+    against the reference's own `nerf` package, on the synthetic case of run_scripts.as_shipped_case; the uint8 images it hands to
+    imageio.imwrite (EV:484-488) are the fixture.  launch/eval_sharded.py --as-shipped must reproduce them."""
+    import tempfile
+    from oracle import run_scripts as RS
+    assert not torch.cuda.is_available(), "the reference script picks cuda when it sees one; the fixture is the CPU result"
+    written, blob = {}, {}
+    with tempfile.TemporaryDirectory() as tmp, RS.script_stubs(written), RI.flame_loader_io():
+        cfg_path, ck_path = RS.as_shipped_case(tmp)
+        ev = RS.import_script("eval_transformed_rays", against="reference")
+        torch.manual_seed(0)
+        RS.run_main(ev, ["--config", cfg_path, "--checkpoint", ck_path, "--savedir", os.path.join(tmp, "out")], max_frames=n_frames)
+        for i in range(n_frames):
+            blob[f"rgb_u8_{i}"] = written[os.path.join(tmp, "out", f"{i:04d}.png")]
+    np.savez_compressed(os.path.join(OUT, "eval_as_shipped.npz"), **blob)
+    print("eval_as_shipped fixture:", {k: (v.shape, int(v.sum())) for k, v in blob.items()})
+
+
 def make_load_flame():
     """load_flame_data (LF:40-211) of the UNMODIFIED reference on the synthetic on-disk dataset of tools/make_synthetic_dataset.py
     (regenerated from its seed by the test), with imageio/cv2 backed as described in ref_import.flame_loader_io."""
@@ -244,6 +264,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "load_flame":
         make_load_flame()
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "eval_as_shipped":
+        make_eval_as_shipped()
         return
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None     # `cases NAME...`: only these 7-tuple fixtures

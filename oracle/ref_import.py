@@ -1,9 +1,11 @@
-"""Import the UNMODIFIED reference `nerf` package from /root/reference (build container only).
+"""Import the UNMODIFIED reference `nerf` package: from /root/reference in the build container, from the archive
+oracle/_ref/nerface_ref.zip (packed by oracle/make_ref.py from that tree, byte for byte; git-ignored, ships with the push)
+on the GPU box.
 
-TEST INFRASTRUCTURE ONLY.  /root/reference does not exist on the GPU box; everything that calls this
-module guards on ``reference_available()``.  Five third-party modules that the reference imports at
-module scope but never calls on the hot path are stubbed; no reference source is
-modified or copied.
+TEST INFRASTRUCTURE ONLY.  ``reference_available()`` = the live tree is there (build container);
+``reference_importable()`` = live tree OR the travelling archive.  Five third-party modules that the reference imports
+at module scope but never calls on the hot path are stubbed; no reference source is modified, and
+none enters the repository history.
 """
 from __future__ import annotations
 
@@ -14,10 +16,31 @@ import sys
 import types
 
 REF_ROOT = "/root/reference/nerface_code/nerf-pytorch"
+REF_ARCHIVE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_ref", "nerface_ref.zip")
 
 
 def reference_available() -> bool:
+    """The live, unpacked reference tree (build container only: configs, command files, everything)."""
     return os.path.isdir(os.path.join(REF_ROOT, "nerf"))
+
+
+def reference_importable() -> bool:
+    """The reference's `nerf` package and its two scripts can be imported: live tree, or the archive that travelled."""
+    return reference_available() or os.path.exists(REF_ARCHIVE)
+
+
+def import_root() -> str:
+    """sys.path entry the unmodified reference modules are imported from (a directory, or the zip: zipimport)."""
+    if reference_available():
+        return REF_ROOT
+    if os.path.exists(REF_ARCHIVE):
+        return REF_ARCHIVE
+    raise RuntimeError("neither /root/reference nor oracle/_ref/nerface_ref.zip is present (python -m oracle.make_ref packs it "
+                       "in the build container)")
+
+
+def reference_kind() -> str:
+    return "live tree /root/reference" if reference_available() else "oracle/_ref/nerface_ref.zip (unmodified files packed by oracle/make_ref.py)"
 
 
 def import_reference():
@@ -26,8 +49,7 @@ def import_reference():
     ``nerf``."""
     if "_ref_nerf" in sys.modules:
         return sys.modules["_ref_nerf"]
-    if not reference_available():
-        raise RuntimeError("reference tree not present (expected only inside the build container)")
+    root = import_root()
     for n in ["pytorch3d", "pytorch3d.transforms", "torchsearchsorted", "cv2", "imageio"]:
         if n not in sys.modules:
             sys.modules[n] = types.ModuleType(n)
@@ -35,11 +57,11 @@ def import_reference():
     saved = {k: v for k, v in sys.modules.items() if k == "nerf" or k.startswith("nerf.")}
     for k in saved:
         del sys.modules[k]
-    sys.path.insert(0, REF_ROOT)
+    sys.path.insert(0, root)
     try:
         mod = importlib.import_module("nerf")
     finally:
-        sys.path.remove(REF_ROOT)
+        sys.path.remove(root)
     # re-home: reference modules live on as _ref_nerf*, the public name is released again
     for k in [k for k in sys.modules if k == "nerf" or k.startswith("nerf.")]:
         sys.modules["_ref_" + k] = sys.modules.pop(k)
@@ -53,13 +75,14 @@ def import_reference_tiny():
     if "_ref_tiny_nerf" in sys.modules:
         return sys.modules["_ref_tiny_nerf"]
     saved = _expose_reference_nerf()
-    sys.path.insert(0, REF_ROOT)
+    root = import_root()
+    sys.path.insert(0, root)
     try:
         import matplotlib
         matplotlib.use("Agg")
         mod = importlib.import_module("tiny_nerf")
     finally:
-        sys.path.remove(REF_ROOT)
+        sys.path.remove(root)
         _hide_reference_nerf(saved)
     sys.modules["_ref_tiny_nerf"] = sys.modules.pop("tiny_nerf")
     return mod
@@ -112,13 +135,14 @@ def import_reference_eval():
         tv, tr = _torchvision_stub()
         sys.modules["torchvision"], sys.modules["torchvision.transforms"] = tv, tr
         added += ["torchvision", "torchvision.transforms"]
-    sys.path.insert(0, REF_ROOT)
+    root = import_root()
+    sys.path.insert(0, root)
     try:
         import matplotlib
         matplotlib.use("Agg")
         mod = importlib.import_module("eval_transformed_rays")
     finally:
-        sys.path.remove(REF_ROOT)
+        sys.path.remove(root)
         _hide_reference_nerf(saved)
         for k in added:
             sys.modules.pop(k, None)

@@ -35,8 +35,14 @@ def _worker(rank, world, port, q):
             p.grad = None if name.startswith("layers_dir.3") else torch.full_like(p, float(rank + 1) * (i + 1))
         table.grad = torch.zeros_like(table)
         table.grad[rank] = float(rank + 1)
-        D.GradientAllReducer(params).reduce()
-        ok = True
+        red = D.GradientAllReducer(params)
+        red.enable_timing()
+        red.reduce()
+        red.reduce()                                      # (averaging the averaged gradients again leaves them unchanged)
+        st = red.stats()
+        live = sum(p.numel() for n_, p in m.named_parameters() if not n_.startswith("layers_dir.3")) + table.numel()
+        ok = st["ranks_seen"] == world and st["bytes_allreduced"] == 4 * live and st["calls"] == 2 and st["allreduce_us"] > 0
+        ok &= st["backend"] == "gloo"
         for i, p in enumerate(params[:-1]):
             name = list(dict(m.named_parameters()))[i]
             if name.startswith("layers_dir.3"):

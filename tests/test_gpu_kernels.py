@@ -414,3 +414,24 @@ def test_one_launch_adam_follows_torch_adam(hip_lib, gpu):
     assert float(oa.state[pa[3]]["step"]) == 3.0 and float(oa.state[pa[0]]["step"]) == 6.0
     with pytest.raises(NotImplementedError):
         nerf.optim.Adam(mk(), lr=1e-3, weight_decay=0.1)
+    # a checkpoint of the reference's torch versions holds `step` as a Python int; a fused / capturable one on the device:
+    # both resume, in step with torch.optim.Adam; version counters move (caches keyed on them see the update); an empty tensor is skipped
+    for conv in (lambda t: int(t.item()), lambda t: t.to(gpu)):
+        sd = ob.state_dict()
+        for st in sd["state"].values():
+            st["step"] = conv(st["step"])
+        pc = [torch.nn.Parameter(b.detach().clone()) for b in pb] + [torch.nn.Parameter(torch.zeros(0, device=gpu))]
+        oc = nerf.optim.Adam(pc[:-1], lr=5e-4)
+        oc.load_state_dict(sd)
+        oc.add_param_group({"params": [pc[-1]]})
+        before = [p._version for p in pc[:-1]]
+        for k, (c_, b) in enumerate(zip(pc, pb)):
+            gr = (torch.randn(shapes[k], generator=g) * 0.01).to(gpu)
+            c_.grad, b.grad = gr.clone(), gr.clone()
+        pc[-1].grad = torch.zeros(0, device=gpu)
+        oc.step()
+        ob.step()
+        assert all(p._version > v for p, v in zip(pc[:-1], before))
+        assert float(oc.state[pc[0]]["step"]) == float(ob.state[pb[0]]["step"]) and not oc.state[pc[0]]["step"].is_cuda
+        for k, (c_, b) in enumerate(zip(pc, pb)):
+            assert float((c_ - b).abs().max() / (b.abs().max() + 1e-12)) < 2e-6, k

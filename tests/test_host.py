@@ -157,8 +157,8 @@ def test_product_has_no_cpu_path():
 
 def test_oracle_is_imported_only_by_the_checkers():
     """oracle/ is test infrastructure: nothing in the product package, the launchers or tools/ may import it; bench.py may only
-    inside its baseline legs (functions cpu_baseline, cpu_baseline_tiny, eager_rocm_baseline) and __graft_entry__ only as the smoke() / build()
-    checker."""
+    inside its baseline legs (functions cpu_baseline + its helper _reference_cpu_run, cpu_baseline_tiny, eager_rocm_baseline) and
+    __graft_entry__ only as the smoke() / build() checker."""
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
     for base in ("4d-facial-avatars_amd", "tools"):
         for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
@@ -168,7 +168,7 @@ def test_oracle_is_imported_only_by_the_checkers():
                     assert not pat.search(src), os.path.join(dirpath, f)
     bench = open(os.path.join(ROOT, "bench.py")).read()
     n_legs = 0
-    for fn in ("def cpu_baseline(", "def cpu_baseline_tiny(", "def eager_rocm_baseline("):
+    for fn in ("def _reference_cpu_run(", "def cpu_baseline(", "def cpu_baseline_tiny(", "def eager_rocm_baseline("):
         leg = bench[bench.index(fn):]
         leg = leg[:leg.index("\ndef ", 1)]
         n_legs += len(pat.findall(leg))
