@@ -417,7 +417,8 @@ def test_one_launch_adam_follows_torch_adam(hip_lib, gpu):
     # a checkpoint of the reference's torch versions holds `step` as a Python int; a fused / capturable one on the device:
     # both resume, in step with torch.optim.Adam; version counters move (caches keyed on them see the update); an empty tensor is skipped
     for conv in (lambda t: int(t.item()), lambda t: t.to(gpu)):
-        sd = ob.state_dict()
+        import copy
+        sd = copy.deepcopy(ob.state_dict())                          # (state_dict() hands out the optimizer's own per-parameter dicts)
         for st in sd["state"].values():
             st["step"] = conv(st["step"])
         pc = [torch.nn.Parameter(b.detach().clone()) for b in pb] + [torch.nn.Parameter(torch.zeros(0, device=gpu))]
