@@ -132,7 +132,7 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     cx.lane = threadIdx.x & 63;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.lds = lds;
-    cx.gsrc = wstream + cx.lane * 16;
+    nfb_ctx_stream(cx, wstream, (unsigned)nfb::STREAM_BF16 * 2u);
     const int h = cx.lane >> 5, c = cx.lane & 31;
     const int64_t p_tile = ((int64_t)blockIdx.x * 4 + cx.wave) * 32;                 // first point of this wave's tile
     const int64_t p_raw = p_tile + c;
@@ -167,9 +167,9 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     const u32x4* mbase = reinterpret_cast<const u32x4*>(saved + (int64_t)S_MASK * n);
 #pragma unroll
     for (int l = 0; l < 9; ++l) mask[l] = mbase[((int64_t)l * n + p) * 2 + h];
-    nfb_issue<nfb::stage_nblk(0)>(cx, cx.gsrc, nfb::stage_blk0(0), 0);
-    nfb_issue<nfb::stage_nblk(1)>(cx, cx.gsrc, nfb::stage_blk0(1), NFB_STAGE_BYTES);
-    nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
+    nfb_issue_w<nfb::stage_nblk(0)>(cx, nfb::stage_blk0(0), 0);
+    nfb_issue_w<nfb::stage_nblk(1)>(cx, nfb::stage_blk0(1), NFB_STAGE_BYTES);
+    nfb_issue_w<nfb::stage_nblk(2)>(cx, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
 
     bf16x8 bh[20], bl[20], th[20], tl[20];
 #if NFB_F16
@@ -192,36 +192,42 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    f32x16 acc[8];
+    // two accumulator sets (deferred saves, nf_mlp_bf16_machinery.inc): dZ of layer l leaves from inside the K loop of layer l+1
+    f32x16 accA[8], accB[8];
     // EXTRA_: a gradient that joins the next layer's operands (d sigma), so that the point's scale covers it
 #if NFB_F16
-#define NFB_BWD_RESCALE(L_, NO_, EXTRA_)                                                                 \
+#define NFB_BWD_RESCALE(L_, acc_, NO_, EXTRA_)                                                           \
     do {                                                                                                 \
-        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc) : 0.0f);                                  \
+        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc_) : 0.0f);                                 \
         G = sgn * nfb_pow2_scale(fmaxf(lm[L_], EXTRA_), invG);                                           \
         invG *= sgn;                                                                                     \
     } while (0)
 #else
-#define NFB_BWD_RESCALE(L_, NO_, EXTRA_) (void)0
+#define NFB_BWD_RESCALE(L_, acc_, NO_, EXTRA_) (void)0
 #endif
-#define NFB_BWD_FINISH(L_, NO_, MASK_, ZSEC_, EXTRA_)                                                    \
+    // layer epilogue: ReLU mask, true gradients (they stay in acc_ until the NEXT layer's K loop has stored them), next operands
+#define NFB_BWD_FINISH(L_, acc_, NO_, MASK_, EXTRA_)                                                     \
     do {                                                                                                 \
-        if ((MASK_) >= 0) nfb_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                    \
-        nfb_scale<NO_>(acc, INV(L_) * invG);                       /* true gradients for dz */            \
-        nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
-        NFB_BWD_RESCALE(L_, NO_, EXTRA_);                                                                \
-        nfb_to_operands<NO_, false>(acc, bh, bl, 0, G);                                                  \
+        if ((MASK_) >= 0) nfb_apply_mask<NO_>(acc_, mask[(MASK_) >= 0 ? (MASK_) : 0]);                   \
+        nfb_scale<NO_>(acc_, INV(L_) * invG);                      /* true gradients for dz */            \
+        NFB_BWD_RESCALE(L_, acc_, NO_, EXTRA_);                                                          \
+        nfb_to_operands<NO_, false>(acc_, bh, bl, 0, G);                                                 \
+    } while (0)
+#define NFB_BWD_RUN(L_, acc_, oh_, ol_, NOP_, prev_, PZSEC_)                                             \
+    do {                                                                                                 \
+        const NfbSaveTarget tg_ = nfb_save_target(dz + (int64_t)(PZSEC_) * n, 32 * (NOP_), p_tile, n, cx.lane); \
+        NFB_LAYER_SAVING(L_, acc_, oh_, ol_, NOP_, prev_, tg_);                                          \
     } while (0)
     // mask indices: h0..h5 -> 0..5, layers_dir.0..2 outputs -> 6..8
-    nfb_zero_tiles<4>(acc);
-    NFB_LAYER(0, acc, th, tl);
-    NFB_BWD_FINISH(0, 4, 8, Z_D2, 0.0f);
-    nfb_zero_tiles<4>(acc);
-    NFB_LAYER(1, acc, bh, bl);
-    NFB_BWD_FINISH(1, 4, 7, Z_D1, 0.0f);
-    nfb_zero_tiles<4>(acc);
-    NFB_LAYER(2, acc, bh, bl);
-    NFB_BWD_FINISH(2, 4, 6, Z_D0, fabsf(d.w));
+    nfb_zero_tiles<4>(accA);
+    NFB_LAYER(0, accA, th, tl);
+    NFB_BWD_FINISH(0, accA, 4, 8, 0.0f);                               // dZ_D2
+    nfb_zero_tiles<4>(accB);
+    NFB_BWD_RUN(1, accB, bh, bl, 4, accA, Z_D2);
+    NFB_BWD_FINISH(1, accB, 4, 7, 0.0f);                               // dZ_D1
+    nfb_zero_tiles<4>(accA);
+    NFB_BWD_RUN(2, accA, bh, bl, 4, accB, Z_D1);
+    NFB_BWD_FINISH(2, accA, 4, 6, fabsf(d.w));                         // dZ_D0
     // d feat = dZ_D0 . layers_dir.0[:, :256] + d sigma * fc_alpha.weight (no activation on feat)
 #pragma unroll
     for (int s = 0; s < 8; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
@@ -232,34 +238,36 @@ NFB_BWD_NAME(k_paper_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { th[9][j] = (nfb_elt)0.f; tl[9][j] = (nfb_elt)0.f; }
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(3, acc, th, tl);
-    NFB_BWD_FINISH(3, 8, -1, Z_FEAT, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(4, acc, bh, bl);
-    NFB_BWD_FINISH(4, 8, 5, Z_L5, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(5, acc, bh, bl);
-    NFB_BWD_FINISH(5, 8, 4, Z_L4, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(6, acc, bh, bl);
-    NFB_BWD_FINISH(6, 8, 3, Z_L3, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(7, acc, bh, bl);
-    NFB_BWD_FINISH(7, 8, 2, Z_L2, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(8, acc, bh, bl);
-    NFB_BWD_FINISH(8, 8, 1, Z_L1, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(9, acc, bh, bl);
-    nfb_apply_mask<8>(acc, mask[0]);
-    nfb_scale<8>(acc, INV(9) * invG);
-    nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L0 * n, 256, p_tile, n);
-    NFB_BWD_RESCALE(9, 8, 0.0f);                                       // only for max |dZ_L0| (the weight-gradient kernel's scale)
+    nfb_zero_tiles<8>(accB);
+    NFB_BWD_RUN(3, accB, th, tl, 4, accA, Z_D0);
+    NFB_BWD_FINISH(3, accB, 8, -1, 0.0f);                              // dZ_FEAT
+    nfb_zero_tiles<8>(accA);
+    NFB_BWD_RUN(4, accA, bh, bl, 8, accB, Z_FEAT);
+    NFB_BWD_FINISH(4, accA, 8, 5, 0.0f);                               // dZ_L5
+    nfb_zero_tiles<8>(accB);
+    NFB_BWD_RUN(5, accB, bh, bl, 8, accA, Z_L5);
+    NFB_BWD_FINISH(5, accB, 8, 4, 0.0f);                               // dZ_L4
+    nfb_zero_tiles<8>(accA);
+    NFB_BWD_RUN(6, accA, bh, bl, 8, accB, Z_L4);
+    NFB_BWD_FINISH(6, accA, 8, 3, 0.0f);                               // dZ_L3
+    nfb_zero_tiles<8>(accB);
+    NFB_BWD_RUN(7, accB, bh, bl, 8, accA, Z_L3);
+    NFB_BWD_FINISH(7, accB, 8, 2, 0.0f);                               // dZ_L2
+    nfb_zero_tiles<8>(accA);
+    NFB_BWD_RUN(8, accA, bh, bl, 8, accB, Z_L2);
+    NFB_BWD_FINISH(8, accA, 8, 1, 0.0f);                               // dZ_L1
+    nfb_zero_tiles<8>(accB);
+    NFB_BWD_RUN(9, accB, bh, bl, 8, accA, Z_L1);
+    nfb_apply_mask<8>(accB, mask[0]);
+    nfb_scale<8>(accB, INV(9) * invG);
+    nfb_save_now<8>(accB, nfb_save_target(dz + (int64_t)Z_L0 * n, 256, p_tile, n, cx.lane), cx.lds + NFB_XPOSE_OFF + cx.wave * NFB_XPOSE_BYTES,
+                    cx.lane);                                          // the last dZ has no K loop behind it
+    NFB_BWD_RESCALE(9, accB, 8, 0.0f);                                 // only for max |dZ_L0| (the weight-gradient kernel's scale)
 #if NFB_F16
     nfb_flush_layer_max<NFB_GS_DRAW + 1>(lm, lmax, seen, cx.lane);
 #endif
 #undef NFB_BWD_FINISH
+#undef NFB_BWD_RUN
 #undef NFB_BWD_RESCALE
 #undef INV
 }

@@ -124,7 +124,7 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     cx.lane = threadIdx.x & 63;
     cx.wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     cx.lds = lds;
-    cx.gsrc = wstream + cx.lane * 16;
+    nfb_ctx_stream(cx, wstream, (unsigned)nfb::STREAM_BF16 * 2u);
     const int h = cx.lane >> 5, c = cx.lane & 31;
     const int64_t p_tile = ((int64_t)blockIdx.x * 4 + cx.wave) * 32;                 // first point of this wave's tile
     const int64_t p_raw = p_tile + c;
@@ -155,9 +155,9 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     const u32x4* mbase = reinterpret_cast<const u32x4*>(saved + (int64_t)S_MASK * n);
 #pragma unroll
     for (int l = 0; l < 5; ++l) mask[l] = mbase[((int64_t)l * n + p) * 2 + h];
-    nfb_issue<nfb::stage_nblk(0)>(cx, cx.gsrc, nfb::stage_blk0(0), 0);
-    nfb_issue<nfb::stage_nblk(1)>(cx, cx.gsrc, nfb::stage_blk0(1), NFB_STAGE_BYTES);
-    nfb_issue<nfb::stage_nblk(2)>(cx, cx.gsrc, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
+    nfb_issue_w<nfb::stage_nblk(0)>(cx, nfb::stage_blk0(0), 0);
+    nfb_issue_w<nfb::stage_nblk(1)>(cx, nfb::stage_blk0(1), NFB_STAGE_BYTES);
+    nfb_issue_w<nfb::stage_nblk(2)>(cx, nfb::stage_blk0(2), 2 * NFB_STAGE_BYTES);
 
     bf16x8 bh[20], bl[20], th[20], tl[20];
 #if NFB_F16
@@ -181,33 +181,38 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
 
-    f32x16 acc[8];
+    // two accumulator sets (deferred saves, nf_mlp_bf16_machinery.inc): dZ of layer l leaves from inside the K loop of layer l+1
+    f32x16 accA[8], accB[8];
     // EXTRA_: a gradient that joins the next layer's operands (d sigma), so that the point's scale covers it
 #if NFB_F16
-#define NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_)                                                              \
+#define NFB_LC_BWD_RESCALE(L_, acc_, NO_, EXTRA_)                                                        \
     do {                                                                                                 \
-        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc) : 0.0f);                                  \
+        lm[L_] = nfb_pair_max(live ? nfb_lane_absmax<NO_>(acc_) : 0.0f);                                 \
         G = sgn * nfb_pow2_scale(fmaxf(lm[L_], EXTRA_), invG);                                           \
         invG *= sgn;                                                                                     \
     } while (0)
 #else
-#define NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_) (void)0
+#define NFB_LC_BWD_RESCALE(L_, acc_, NO_, EXTRA_) (void)0
 #endif
-#define NFB_LC_BWD_FINISH(L_, NO_, MASK_, ZSEC_, EXTRA_)                                                 \
+#define NFB_LC_BWD_FINISH(L_, acc_, NO_, MASK_, EXTRA_)                                                  \
     do {                                                                                                 \
-        if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc, mask[(MASK_) >= 0 ? (MASK_) : 0]);                 \
-        nfb_scale<NO_>(acc, INV(L_) * invG);                       /* true gradients for dz */            \
-        nfb_save_tiles<NO_>(cx, acc, dz + (int64_t)(ZSEC_) * n, 32 * (NO_), p_tile, n);                  \
-        NFB_LC_BWD_RESCALE(L_, NO_, EXTRA_);                                                             \
-        nfb_to_operands<NO_, false>(acc, bh, bl, 0, G);                                                  \
+        if ((MASK_) >= 0) nfb_lc_apply_mask<NO_>(acc_, mask[(MASK_) >= 0 ? (MASK_) : 0]);                \
+        nfb_scale<NO_>(acc_, INV(L_) * invG);                      /* true gradients for dz: stored by the next layer's K loop */ \
+        NFB_LC_BWD_RESCALE(L_, acc_, NO_, EXTRA_);                                                       \
+        nfb_to_operands<NO_, false>(acc_, bh, bl, 0, G);                                                 \
+    } while (0)
+#define NFB_LC_BWD_RUN(L_, acc_, oh_, ol_, NOP_, prev_, PZSEC_)                                          \
+    do {                                                                                                 \
+        const NfbSaveTarget tg_ = nfb_save_target(dz + (int64_t)(PZSEC_) * n, 32 * (NOP_), p_tile, n, cx.lane); \
+        NFB_LAYER_SAVING(L_, acc_, oh_, ol_, NOP_, prev_, tg_);                                          \
     } while (0)
     // mask indices: layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
-    nfb_zero_tiles<4>(acc);
-    NFB_LAYER(0, acc, th, tl);
-    NFB_LC_BWD_FINISH(0, 4, 4, Z_DIR, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(1, acc, bh, bl);
-    NFB_LC_BWD_FINISH(1, 8, 3, Z_FEAT, fabsf(d.w));
+    nfb_zero_tiles<4>(accA);
+    NFB_LAYER(0, accA, th, tl);
+    NFB_LC_BWD_FINISH(0, accA, 4, 4, 0.0f);                            // dZ_DIR
+    nfb_zero_tiles<8>(accB);
+    NFB_LC_BWD_RUN(1, accB, bh, bl, 4, accA, Z_DIR);
+    NFB_LC_BWD_FINISH(1, accB, 8, 3, fabsf(d.w));                      // dZ_FEAT
     // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight (fc_alpha reads x), gated by layers_xyz.2's ReLU
 #pragma unroll
     for (int s = 0; s < 16; ++s) { th[s] = bh[s]; tl[s] = bl[s]; }
@@ -218,24 +223,26 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) { th[17][j] = (nfb_elt)0.f; tl[17][j] = (nfb_elt)0.f; }
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(2, acc, th, tl);
-    NFB_LC_BWD_FINISH(2, 8, 2, Z_X2, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(3, acc, bh, bl);
-    NFB_LC_BWD_FINISH(3, 8, 1, Z_X1, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(4, acc, bh, bl);
-    NFB_LC_BWD_FINISH(4, 8, 0, Z_X0, 0.0f);
-    nfb_zero_tiles<8>(acc);
-    NFB_LAYER(5, acc, bh, bl);                                         // layer1 has no activation: dZ = d(out)
-    nfb_scale<8>(acc, INV(5) * invG);
-    nfb_save_tiles<8>(cx, acc, dz + (int64_t)Z_L1 * n, 256, p_tile, n);
-    NFB_LC_BWD_RESCALE(5, 8, 0.0f);                                    // only for max |dZ_L1| (the weight-gradient kernel's scale)
+    nfb_zero_tiles<8>(accA);
+    NFB_LC_BWD_RUN(2, accA, th, tl, 8, accB, Z_FEAT);
+    NFB_LC_BWD_FINISH(2, accA, 8, 2, 0.0f);                            // dZ_X2
+    nfb_zero_tiles<8>(accB);
+    NFB_LC_BWD_RUN(3, accB, bh, bl, 8, accA, Z_X2);
+    NFB_LC_BWD_FINISH(3, accB, 8, 1, 0.0f);                            // dZ_X1
+    nfb_zero_tiles<8>(accA);
+    NFB_LC_BWD_RUN(4, accA, bh, bl, 8, accB, Z_X1);
+    NFB_LC_BWD_FINISH(4, accA, 8, 0, 0.0f);                            // dZ_X0
+    nfb_zero_tiles<8>(accB);
+    NFB_LC_BWD_RUN(5, accB, bh, bl, 8, accA, Z_X0);                    // layer1 has no activation: dZ = d(out)
+    nfb_scale<8>(accB, INV(5) * invG);
+    nfb_save_now<8>(accB, nfb_save_target(dz + (int64_t)Z_L1 * n, 256, p_tile, n, cx.lane), cx.lds + NFB_XPOSE_OFF + cx.wave * NFB_XPOSE_BYTES,
+                    cx.lane);                                          // the last dZ has no K loop behind it
+    NFB_LC_BWD_RESCALE(5, accB, 8, 0.0f);                              // only for max |dZ_L1| (the weight-gradient kernel's scale)
 #if NFB_F16
     nfb_flush_layer_max<NFB_GS_DRAW + 1>(lm, lmax, seen, cx.lane);
 #endif
 #undef NFB_LC_BWD_FINISH
+#undef NFB_LC_BWD_RUN
 #undef NFB_LC_BWD_RESCALE
 #undef INV
 }

@@ -1,5 +1,8 @@
 // Training (activation-saving) instantiation of the split-bf16 fused forward of the second model family; its own translation
 // unit so that it cannot perturb the code generation of the inference kernel (nf_mlp_lcode_bf16.hip).
+#ifndef NFB_TILE_GROUP
+#define NFB_TILE_GROUP 4          // two accumulator sets (deferred saves): A fragments of 4 output tiles at a time, no spills (8: 11 spilled registers)
+#endif
 #include "nf_mlp_lcode_bf16_common.h"
 
 #define NFB_SAVE 1

@@ -10,6 +10,7 @@
 #include "nf_pack.h"
 
 #define NFB_SAVE 1
+#define NFB_LC_X2_EARLY 1          // see nf_mlp_lcode_bf16_kernel.inc
 #define NFB_KERNEL_NAME k_lcode_mlp_fwd_f16_train
 #include "nf_mlp_lcode_bf16_kernel.inc"
 
