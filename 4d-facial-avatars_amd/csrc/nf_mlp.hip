@@ -21,12 +21,6 @@
 #include "nf_mlp_stream.h"
 #include "nf_pack.h"
 
-#ifndef NF_FWD_PERSIST
-#define NF_FWD_PERSIST 1
-#endif
-#ifndef NF_FWD_STREAM
-#define NF_FWD_STREAM 1      // 0 (with NF_FWD_PERSIST=0): the round-2 inference kernel (block epilogue per layer), the A/B baseline of profiles/r03_mlp_f32_stream.md
-#endif
 
 // =================================================================================================
 // pack: gather the 26 nn.Parameter storages into the fragment-ordered image
@@ -178,10 +172,6 @@ extern "C" int nf_paper_condition(const float* packed, const float* expr76, cons
 // =================================================================================================
 // forward
 // =================================================================================================
-#ifndef NF_FWD_PREFETCH_IN
-#define NF_FWD_PREFETCH_IN 0     // 1: persistent form only -- the next block's z / ray loads are issued before layers_dir.0 of the current one.
-                                 // Measured once (profiles/r03_mlp_f32_stream.md section 6): bit-identical, 86.5 vs 86.3 ms -- no gain, off.
-#endif
 struct NfPointIn {
     float z, ox, oy, oz, dx, dy, dz, dv;
 };
@@ -210,12 +200,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-#if NF_FWD_PERSIST
     // persistent form: one workgroup per CU walks the point blocks with the grid's stride (no workgroup dispatch between blocks)
-#if NF_FWD_PREFETCH_IN
-    NfPointIn in_cur[NT], in_nxt[NT];
-    nf_load_point_in<NT>(in_cur, ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT), c, n_points, S, ro, rd, rd_view, z);   // (clamped: harmless past the end)
-#endif
 #pragma unroll 1
     for (int64_t blk = blockIdx.x;; blk += gridDim.x) {
     const int64_t p0 = (blk * NF_MLP_WAVES + wave) * (16 * NT);
@@ -224,28 +209,12 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     asm volatile("" : "+s"(opaque0));
     const f32x4* W = reinterpret_cast<const f32x4*>(packed) + opaque0;
     const float* cond = cond_ + opaque0;
-#else
-    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
-    if (p0 >= n_points) return;                       // wave-uniform; no barriers anywhere below
-    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
-    const float* cond = cond_;
-#endif
 
     // ---- inputs: pts = ro + rd*z (T:78), PE fragments, dir fragment -----------------------------
     f32x4 pe[NT][4];
     f32x4 dirf[NT][1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
-#if NF_FWD_PERSIST && NF_FWD_PREFETCH_IN
-        const float zz = in_cur[t].z;
-        const float px = nf_add(in_cur[t].ox, nf_mul(in_cur[t].dx, zz));
-        const float py = nf_add(in_cur[t].oy, nf_mul(in_cur[t].dy, zz));
-        const float pz = nf_add(in_cur[t].oz, nf_mul(in_cur[t].dz, zz));
-        nf_encode_point(px, py, pz, g, pe[t]);
-        float s, cs;
-        sincosf(nf_mul(in_cur[t].dv, (float)(1 << g)), &s, &cs);
-        dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
-#else
         int64_t p = p0 + 16 * t + c;
         if (p >= n_points) p = n_points - 1;
         const int64_t ray = p / S;
@@ -258,11 +227,9 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         float s, cs;
         sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
-#endif
     }
 
     f32x4 acc[NT][16];
-#if NF_FWD_STREAM
     // Layer-streamed form (nf_mlp_stream.h): every layer ends in nf_tail, which writes the raw accumulators to the slab tile by
     // tile under the last chunk's MFMAs and fetches the next layer's bias, first weights and first B fragment; every layer starts
     // with the bias as the C operand of its first MFMAs; the ReLU is applied where the slab is read.
@@ -317,9 +284,6 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
     nf_tail<NT, 16, 16, 9, 1>(acc, st.wb, bj, st, Wi, OFF_D0 / 4, Ci, B_D0, act4, lane);
-#if NF_FWD_PERSIST && NF_FWD_PREFETCH_IN
-    nf_load_point_in<NT>(in_nxt, ((blk + gridDim.x) * NF_MLP_WAVES + wave) * (16 * NT), c, n_points, S, ro, rd, rd_view, z);   // lands under the four dir layers
-#endif
     // ---- layers_dir.0 : [feat | dir slots] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2) -----------------------
     float sigma_raw[NT];
     {
@@ -346,59 +310,6 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
     nf_pending_b<NT, true>(bj, st);
     nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
-#else
-#define NF_FINISH_LAYER(NO_, RELU_, SEC_, WIDTH_)                                                   \
-    do {                                                                                            \
-        if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                   \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                              \
-    } while (0)
-    // ---- layers_xyz.0 : PE(64 slots) -> 256, ReLU ------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
-    NF_FINISH_LAYER(16, true, S_H0, 256);
-    // ---- layers_xyz.1, .2 ------------------------------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L1 / 4, 16, act4, lane);
-    NF_FINISH_LAYER(16, true, S_H1, 256);
-    nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L2 / 4, 16, act4, lane);
-    NF_FINISH_LAYER(16, true, S_H2, 256);
-    // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
-    NF_FINISH_LAYER(16, true, S_H3, 256);
-    // ---- layers_xyz.4, .5 ------------------------------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L4 / 4, 16, act4, lane);
-    NF_FINISH_LAYER(16, true, S_H4, 256);
-    nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L5 / 4, 16, act4, lane);
-    NF_FINISH_LAYER(16, true, S_H5, 256);
-    // ---- fc_feat (no activation, M:250) ------------------------------------------------------------
-    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
-    NF_FINISH_LAYER(16, false, S_FEAT, 256);
-    // ---- layers_dir.0 : [feat | dir slots] -> 128, ReLU; tile 8 row 0 = fc_alpha(feat) (Q2) ----------
-    nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
-    nf_mma_from_lds<NT, 9>(acc, W + OFF_D0 / 4, 16, act4, lane);
-    nf_mma_from_regs<NT, 9, 1>(acc, W + OFF_D0 / 4 + 16 * 9 * 64, dirf, lane);
-    float sigma_raw[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
-    NF_FINISH_LAYER(8, true, S_D0, 128);
-    // ---- layers_dir.1, .2 -----------------------------------------------------------------------------
-    nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_D1 / 4, 8, act4, lane);
-    NF_FINISH_LAYER(8, true, S_D1, 128);
-    nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_D2 / 4, 8, act4, lane);
-    NF_FINISH_LAYER(8, true, S_D2, 128);
-#undef NF_FINISH_LAYER
-    // ---- fc_rgb -------------------------------------------------------------------------------------------
-    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
-#endif
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -407,13 +318,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
                 reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
         }
     }
-#if NF_FWD_PERSIST
-#if NF_FWD_PREFETCH_IN
-#pragma unroll
-    for (int t = 0; t < NT; ++t) in_cur[t] = in_nxt[t];
-#endif
     }
-#endif
 }
 
 // Training forward (exact f32): the same arithmetic as k_paper_mlp_fwd, plus everything the backward needs in `saved`
@@ -618,7 +523,7 @@ static int nf_launch_fwd(const float* packed, const float* cond, const float* ro
         hipLaunchKernelGGL((k_paper_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
-        hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)(NF_FWD_PERSIST ? (grid < nf_cu_count() ? grid : nf_cu_count()) : grid)), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+        hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)(grid < nf_cu_count() ? grid : nf_cu_count())), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
     NF_RETURN_LAUNCH();
 }

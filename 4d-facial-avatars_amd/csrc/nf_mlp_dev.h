@@ -212,11 +212,7 @@ __device__ __forceinline__ void nf_encode_point(float px, float py, float pz, in
             const int freq = pidx / 3, comp = pidx - 3 * freq;
             const float x = comp == 0 ? px : (comp == 1 ? py : pz);
             float s, cs;
-#ifdef NF_ABL_NOPE
-            s = nf_mul(x, (float)(1 << freq)); cs = s + 1.0f;          // timing ablation (results invalid)
-#else
             sincosf(nf_mul(x, (float)(1 << freq)), &s, &cs);
-#endif
             v[2 * h] = s;
             v[2 * h + 1] = cs;
         }

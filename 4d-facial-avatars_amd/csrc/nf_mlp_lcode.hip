@@ -9,10 +9,6 @@
 #include "nf_mlp_dev.h"
 #include "nf_mlp_stream.h"
 
-#ifndef NF_LCODE_STREAM
-#define NF_LCODE_STREAM 0      // 1: the second family's f32 inference kernel in layer-streamed form (end of round 3: five parity tests pass on the variant
-                               // build, timing and the full suite pending -- profiles/r03_mlp_f32_stream.md section 6)
-#endif
 #include "nf_mlp_lcode_layout.h"
 #include "nf_pack.h"
 
@@ -141,7 +137,6 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
     }
     f32x4 acc[NT][16];
-#if NF_LCODE_STREAM
     // Layer-streamed form (nf_mlp_stream.h; the paper model's k_paper_mlp_fwd is the template).  layers_xyz.2's output feeds fc_alpha AND
     // fc_feat: fc_alpha's tail stores nothing (NO_ST = 0), so fc_feat reads the same slab again.
     NfStream<NT> st;
@@ -192,40 +187,6 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
     nf_pending_b<NT, true>(bj, st);
     nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
-#else
-#define NF_LC_FINISH(NO_, RELU_, SEC_, WIDTH_)                                                        \
-    do {                                                                                              \
-        if (RELU_) nf_relu_inplace<NT, NO_>(acc);                                                     \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                \
-    } while (0)
-    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
-    NF_LC_FINISH(16, false, S_L1, 256);
-    nf_init_acc<NT, 16>(acc, cond + B_X0, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_X0 / 4, 16, act4, lane);
-    NF_LC_FINISH(16, true, S_X0, 256);
-    nf_init_acc<NT, 16>(acc, cond + B_X1, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_X1 / 4, 16, act4, lane);
-    NF_LC_FINISH(16, true, S_X1, 256);
-    nf_init_acc<NT, 16>(acc, cond + B_X2, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_X2 / 4, 16, act4, lane);
-    NF_LC_FINISH(16, true, S_X2, 256);
-    nf_init_acc<NT, 1>(acc, cond + B_ALPHA, lane);                       // fc_alpha(x)
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_ALPHA / 4, 16, act4, lane);
-    float sigma_raw[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
-    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);                       // feat = relu(fc_feat(x))
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
-    NF_LC_FINISH(16, true, S_FEAT, 256);
-    nf_init_acc<NT, 8>(acc, cond + B_DIR, lane);                         // relu(layers_dir.0([feat | dir]))
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_DIR / 4, 16, act4, lane);
-    nf_mma_from_regs<NT, 8, 1>(acc, W + OFF_DIR / 4 + 16 * 8 * 64, dirf, lane);
-    NF_LC_FINISH(8, true, S_DIR, 128);
-#undef NF_LC_FINISH
-    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
-#endif
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

@@ -99,14 +99,6 @@ __device__ __forceinline__ void nf_chunk(f32x4 (&acc)[NT][16], const f32x4 (&w)[
         else if ((n) == 6) __builtin_amdgcn_sched_group_barrier(mask, 6, 0);           \
     } while (0)
 
-// timing ablations (results invalid): no weight loads / no slab reads inside the K loops
-#ifndef NF_ABL_NOLOAD
-#define NF_ABL_NOLOAD 0
-#endif
-#ifndef NF_ABL_NOLDS
-#define NF_ABL_NOLDS 0
-#endif
-
 // What else rides in a K loop.  The inference kernel: nothing.  The training forward: the deferred copy of the slab the loop reads
 // (the previous layer's output) to `saved`, PER instructions per step -- the head chunk is step 0, loop iteration j is step j; the
 // rows of step j + 1 are read from LDS during step j and stored under the first chunk of step j + 1 (NfSlabCopy, nf_mlp_dev.h:
@@ -180,10 +172,10 @@ __device__ __forceinline__ void nf_half(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
 #pragma unroll
         for (int t = 0; t < NT; ++t) bp[t] = b[t];
     }
-    if (!NF_ABL_NOLDS || FIRST) nf_read_b<NT>(rawn, act4, lane, ni_next);
+    nf_read_b<NT>(rawn, act4, lane, ni_next);
     const Side rows = side;                       // (the rows this half stores: a head chunk also reads the next ones over them)
     if (RD) side.reads(step);                     // (source order = the order the groups below ask for: LDS reads, loads, stores)
-    if (!NF_ABL_NOLOAD || FIRST) nf_load_w16<NO>(wn, W, wsrc, lane);
+    nf_load_w16<NO>(wn, W, wsrc, lane);
     if (ST) rows.stores(step);
     nf_chunk<NT, NO, FIRST>(acc, w, b, bias);
     NF_SGB_N(0x100, NT + NR);

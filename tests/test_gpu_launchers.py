@@ -155,7 +155,12 @@ def test_bench_two_ranks_one_gpu_gloo(hip_lib, gpu):
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512 * 512) < 1.0                    # two ranks x one frame each
     assert "split_f16" in d and "split_bf16" in d and "cpu_baseline" not in d
-    assert set(k for k in d["train"] if k != "workload") == {"f32", "f16x3", "bf16x3"}
+    assert set(k for k in d["train"] if k not in ("workload", "allreduce")) == {"f32", "f16x3", "bf16x3"}
+    # evidence of the N > 1 path on the line itself: ranks the communicator saw, bytes and time of the flat all-reduce
+    ar = d["train"]["allreduce"]
+    assert d["ranks_seen"] == 2 and ar["ranks_seen"] == 2 and ar["backend"] == "gloo" and ar["allreduce_us"] > 0
+    assert ar["bytes_allreduced"] == 4 * (2 * 552196 + 1000 * 32)          # live parameters of both models + the latent table
+    assert d["summary"]["train_bytes_allreduced"] == ar["bytes_allreduced"] and d["summary"]["ranks_seen"] == 2
     assert "data parallel over 2 GPUs" in d["train"]["workload"]
     assert d["roofline"]["traffic"] is None                                                     # PMC passes are an N = 1 extra
 
@@ -199,6 +204,10 @@ def test_rccl_single_rank_runs_every_collective(hip_lib, gpu, tmp_path):
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["roofline"]["bound"] == "mfma" and len(d["roofline"]["kernels"]) == 3
+    # RCCL really ran the flat all-reduce on device memory: the line says how many ranks the communicator saw, what moved, how long it took
+    assert d["ranks_seen"] == 1 and d["allreduce"]["backend"] == "nccl" and d["allreduce"]["calls"] == 4
+    assert d["bytes_allreduced"] == 4 * (2 * 552196 + 1000 * 32) and d["allreduce_us"] > 0
+    assert d["summary"]["allreduce_us"] == d["allreduce_us"]
 
 
 def test_eight_ranks_one_gpu_gloo(hip_lib, gpu, tmp_path):
@@ -247,6 +256,7 @@ def test_eight_ranks_one_gpu_gloo(hip_lib, gpu, tmp_path):
     assert r.returncode == 0, r.stderr.decode()[-3000:]
     d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
     assert d["n_gpus"] == 8 and d["config"]["rays_per_step"] == 8 * 2048 and d["value"] > 0
+    assert d["ranks_seen"] == 8 and d["allreduce"]["calls"] == 3 and d["bytes_allreduced"] == 4 * (2 * 552196 + 1000 * 32) and d["allreduce_us"] > 0
 
 
 def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
