@@ -437,6 +437,204 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
     if (on) for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = srt[i];
 }
 
+// ---------------------------------------------------------------------------------------------
+// K6+K7, the shipped sizes (Nc <= 128, Nf <= 128: 64 + 128 in eval, 64 + 64 in training): the same results as
+// k_resample_merge from a wave that never waits for the block and never runs one lane alone.
+//   * the torch-exact CDF table (nf_build_cdf's arithmetic) without block barriers -- the tables are wave-private and one
+//     wave's LDS instructions execute in order -- and with the sequential DOUBLE cumsum (62 dependent adds on one lane)
+//     replaced by a wave prefix sum in double WHERE THAT IS EXACT: if every pdf entry is 0 or >= 2^-28 and their sum is
+//     below 2, every partial sum is a multiple of 2^-51 below 2, i.e. representable in double -- no addition rounds, so
+//     the association order cannot matter and the scan equals torch's sequential loop bit for bit.  (pdf = (w + 1e-5) / sum
+//     >= 1.6e-7 for weights in [0, 1]: the guard holds for every ray of the hot path; any other input takes the one-lane loop.)
+//   * the Nf samples are sorted in registers (bitonic network over 2 values per lane, cross-lane exchanges), the coarse depths
+//     are sorted already (stratified samples; checked, else the general kernel's full sort runs), and the two lists are MERGED
+//     by rank: out[i + #{B < A[i]}] = A[i], out[j + #{A <= B[j]}] = B[j] (binary searches, no barriers).  The sorted multiset
+//     is what torch.sort returns (T:126 keeps the values only), whatever the algorithm.
+// ---------------------------------------------------------------------------------------------
+#define NF_RS_MAXC 128
+#define NF_RS_MAXF 128
+__device__ __forceinline__ double nf_shfl_up_f64(double v, int d) {
+    const unsigned long long b = __double_as_longlong(v);
+    const unsigned lo = __shfl_up((unsigned)b, d, 64), hi = __shfl_up((unsigned)(b >> 32), d, 64);
+    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
+}
+// wave-private version of nf_build_cdf (same arithmetic, see there); n_w <= NF_RS_MAXC - 2; every lane of the wave calls it
+__device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_row, int n_w, float* lds_cdf) {
+    const int lane = nf_lane();
+    float* x = lds_cdf + 1;
+    for (int i = lane; i < n_w; i += 64) x[i] = nf_add(w_row[i], 1e-5f);
+    __builtin_amdgcn_wave_barrier();
+    float sum;
+    if (n_w < 8) {
+        float p[4] = {0.f, 0.f, 0.f, 0.f};
+        const int q = n_w >> 2;
+        for (int i = 0; i < q; ++i)
+            for (int k = 0; k < 4; ++k) p[k] = nf_add(p[k], x[4 * i + k]);
+        for (int i = q * 4; i < n_w; ++i) p[0] = nf_add(p[0], x[i]);
+        sum = nf_add(nf_add(nf_add(p[0], p[1]), p[2]), p[3]);                 // (every lane computes the same value)
+    } else {
+        const int V = n_w >> 3, q = V >> 2, k = (lane >> 3) & 3, l = lane & 7;
+        float P = 0.0f;                                     // lanes 0..31: P[k][l]
+        for (int i = 0; i < q; ++i) P = nf_add(P, x[((4 * i + k) << 3) + l]);
+        if (k == 0) for (int i = q * 4; i < V; ++i) P = nf_add(P, x[(i << 3) + l]);
+        const float p1 = __shfl(P, 8 + l, 64), p2 = __shfl(P, 16 + l, 64), p3 = __shfl(P, 24 + l, 64);
+        P = nf_add(nf_add(nf_add(P, p1), p2), p3);          // meaningful in lanes 0..7
+        float fin = 0.0f;
+        for (int i = V << 3; i < n_w; ++i) fin = nf_add(fin, x[i]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) fin = nf_add(fin, __shfl(P, j, 64));
+        sum = __shfl(fin, 0, 64);
+    }
+    // pdf, and the exactness guard of the parallel cumsum
+    float v[2];
+    bool ok = true;
+    float mag = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        v[r] = i < n_w ? nf_div(x[i], sum) : 0.0f;
+        ok = ok && (v[r] == 0.0f || (fabsf(v[r]) >= 0x1p-28f && fabsf(v[r]) < 2.0f));     // (NaN fails)
+        mag += fabsf(v[r]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mag += __shfl_xor(mag, o, 64);
+    ok = ok && mag < 1.9f;
+    if (__all(ok)) {
+        double carry = 0.0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            double a = (double)v[r];
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const double up = nf_shfl_up_f64(a, d);
+                if (lane >= d) a += up;                     // exact (see above): any order gives torch's sequential result
+            }
+            a += carry;
+            const int i = lane + 64 * r;
+            if (i < n_w) x[i] = (float)a;
+            const unsigned long long b = __double_as_longlong(a);
+            carry = __longlong_as_double(((unsigned long long)__shfl((unsigned)(b >> 32), 63, 64) << 32) | __shfl((unsigned)b, 63, 64));
+        }
+        if (lane == 0) lds_cdf[0] = 0.0f;
+    } else {
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < n_w) x[i] = v[r]; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) {
+            lds_cdf[0] = 0.0f;
+            double acc = 0.0;
+            for (int i = 0; i < n_w; ++i) { acc += (double)x[i]; x[i] = (float)acc; }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ascending bitonic sort of 128 values held as v[r] = element 64 r + lane
+__device__ __forceinline__ void nf_sort128_regs(float (&v)[2], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) {                                  // elements lane and 64 + lane: both directions "up" (k = 128)
+                const float lo = fminf(v[0], v[1]), hi = fmaxf(v[0], v[1]);
+                v[0] = lo; v[1] = hi;
+            } else {
+#pragma unroll
+                for (int r = 0; r < 2; ++r) {
+                    const float o = __shfl_xor(v[r], j, 64);
+                    const bool lower = (lane & j) == 0, up = k == 128 ? true : ((lane & k) == 0);
+                    v[r] = (lower == up) ? fminf(v[r], o) : fmaxf(v[r], o);
+                }
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_resample_merge_small(const float* __restrict__ zc, const float* __restrict__ wc,
+                                                              const float* __restrict__ u, int64_t u_stride, int64_t n_rays,
+                                                              int nc, int nf, float* __restrict__ z_samples,
+                                                              float* __restrict__ z_fine) {
+    __shared__ float lds[NF_RAYS_PER_BLOCK][3 * NF_RS_MAXC + NF_RS_MAXF + NF_RS_MAXC + NF_RS_MAXF];
+    const int lane = nf_lane(), wv = threadIdx.x >> 6;
+    const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
+    if (ray >= n_rays) return;                              // wave-uniform; no block barrier below
+    float* cdf = lds[wv];
+    float* lb = cdf + NF_RS_MAXC;
+    float* A = lb + NF_RS_MAXC;                             // coarse depths (nc)
+    float* B = A + NF_RS_MAXC;                              // sorted samples (nf)
+    float* out = B + NF_RS_MAXF;                            // merged (nc + nf)
+    const int n_bins = nc - 1, nt = nc + nf;
+    nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf);
+    bool sorted = true;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const float zi = zc[ray * nc + i];
+            A[i] = zi;
+            if (i < n_bins) {
+                const float zn = zc[ray * nc + i + 1];
+                lb[i] = nf_mul(0.5f, nf_add(zn, zi));
+                sorted = sorted && zi <= zn;
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    float v[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int j = lane + 64 * r;
+        v[r] = INFINITY;
+        if (j < nf) {
+            v[r] = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j]);
+            if (z_samples) z_samples[ray * nf + j] = v[r];
+        }
+    }
+    if (!__all(sorted)) {                                   // coarse depths not ascending (no caller on the hot path produces such a row):
+        const int np2 = nf_next_pow2(nt);                   // sort the concatenation like k_resample_merge does, wave-private
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int j = lane + 64 * r; if (j < nf) out[nc + j] = v[r]; }
+        for (int i = lane; i < nc; i += 64) out[i] = A[i];
+        for (int i = nt + lane; i < np2; i += 64) out[i] = INFINITY;
+        __builtin_amdgcn_wave_barrier();
+        for (int k = 2; k <= np2; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int t = lane; t < (np2 >> 1); t += 64) {
+                    const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
+                    const bool up = (i & k) == 0;
+                    const float a = out[i], b = out[q];
+                    if ((a > b) == up) { out[i] = b; out[q] = a; }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = out[i];
+        return;
+    }
+    nf_sort128_regs(v, lane);
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { const int j = lane + 64 * r; if (j < nf) B[j] = v[r]; }
+    __builtin_amdgcn_wave_barrier();
+    // merge by rank
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        if (i < nc) {
+            const float a = A[i];
+            int lo = 0, hi = nf;                            // #{B < a}
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (B[mid] < a) lo = mid + 1; else hi = mid; }
+            out[i + lo] = a;
+        }
+        if (i < nf) {
+            const float b = v[r];                           // B[i]
+            int lo = 0, hi = nc;                            // #{A <= b}
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] <= b) lo = mid + 1; else hi = mid; }
+            out[i + lo] = b;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = out[i];
+}
+
 extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
                                  int64_t n_rays, int n_coarse, int n_fine, float* z_samples, float* z_fine,
                                  nf_stream_t stream) {
@@ -446,6 +644,11 @@ extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, c
         return NF_EINVAL;
     const int64_t grid = (n_rays + NF_RAYS_PER_BLOCK - 1) / NF_RAYS_PER_BLOCK;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    if (n_coarse <= NF_RS_MAXC && n_fine <= NF_RS_MAXF) {
+        hipLaunchKernelGGL(k_resample_merge_small, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), z_coarse, w_coarse, u, u_row_stride,
+                           n_rays, n_coarse, n_fine, z_samples, z_fine);
+        NF_RETURN_LAUNCH();
+    }
     hipLaunchKernelGGL(k_resample_merge, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), z_coarse, w_coarse, u, u_row_stride,
                        n_rays, n_coarse, n_fine, z_samples, z_fine);
     NF_RETURN_LAUNCH();

@@ -226,6 +226,50 @@ def test_sort_rows(hip_lib, gpu):
     assert torch.equal(ops.sort_rows(x.to(gpu)).cpu(), torch.sort(x, dim=-1)[0])
 
 
+def test_resample_merge_fast_path_is_bit_identical(hip_lib, gpu):
+    """k_resample_merge_small (shipped sizes: wave scan in double behind an exactness guard, register sort of the samples, merge by
+    rank) against the separately verified kernels -- z_samples must EQUAL k_sample_pdf's (whose table / indices are array_equal to
+    torch-CPU's, test_sample_pdf_bit_exact) and z_fine must EQUAL k_sort_rows(cat) -- bit for bit, at 64+128, 64+64, ragged sizes, the
+    golden edge rows, rows whose pdf fails the exactness guard (dynamic range > 2^28: the one-lane double loop runs) and rows whose
+    coarse depths are not ascending (the in-kernel full sort runs)."""
+    from nerf import ops
+    g = torch.Generator().manual_seed(21)
+
+    def check(z_c, w_c, nf, u):
+        z_f, z_s = ops.resample_merge(z_c.to(gpu), w_c.to(gpu), nf, None if u is None else u.to(gpu), want_samples=True)
+        bins = 0.5 * (z_c[:, 1:] + z_c[:, :-1])
+        want_s = ops.sample_pdf(bins.to(gpu), w_c[:, 1:-1].contiguous().to(gpu), nf, None if u is None else u.to(gpu))
+        assert torch.equal(z_s, want_s)
+        want_f = ops.sort_rows(torch.cat((z_c.to(gpu), want_s), dim=-1).contiguous())
+        assert torch.equal(z_f, want_f)
+        assert torch.equal(z_f.cpu(), torch.sort(torch.cat((z_c, want_s.cpu()), -1), -1)[0])
+
+    for n_rays, nc, nf in ((4099, 64, 128), (2048, 64, 64), (37, 5, 7), (130, 128, 128), (9, 3, 1), (64, 33, 100)):
+        z_c = torch.sort(torch.rand((n_rays, nc), generator=g) * 0.6 + 0.2, dim=-1)[0]
+        w_c = torch.rand((n_rays, nc), generator=g) ** 6                      # a few spikes, many near-zero weights
+        w_c[::7] = 0.0                                                         # all-zero rows (uniform pdf)
+        w_c[1::7, nc // 2] = 1.0
+        u = torch.rand((n_rays, nf), generator=g)
+        if nf >= 3:
+            u[0, :3] = torch.tensor([0.0, 1.0, 0.999999])
+        check(z_c, w_c, nf, u)
+        check(z_c, w_c, nf, None)                                              # det: linspace abscissae
+    # exactness guard fails: one weight of 1e7 makes the other pdf entries ~1e-12 < 2^-28 -> sequential double cumsum
+    z_c = torch.sort(torch.rand((50, 64), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    w_c = torch.rand((50, 64), generator=g)
+    w_c[:, 20] = 1e7
+    w_c[5] = -2e-5                                                             # negative weights: pdf entries of both signs
+    check(z_c, w_c, 128, torch.rand((50, 128), generator=g))
+    # coarse depths not ascending (no caller on the hot path does this): the result is still sort(cat)
+    z_c = torch.rand((20, 64), generator=g) * 0.6 + 0.2
+    check(z_c, torch.rand((20, 64), generator=g), 128, torch.rand((20, 128), generator=g))
+    # golden edge rows of the reference's own sample_pdf_2 fixture, through the fused kernel (bins -> depths: z = bins padded by one)
+    gd = np.load(f"{GOLD}/pe_pdf.npz")
+    bins, w, u = (torch.from_numpy(gd[k]) for k in ("bins", "w", "u"))
+    z_c = torch.cat((bins[:, :1], bins), dim=-1)                               # 64 depths whose interior midpoints are not the bins, fine
+    check(z_c.contiguous(), torch.cat((w[:, :1], w, w[:, :1]), dim=-1).contiguous(), 128, u)
+
+
 def test_resample_merge(hip_lib, gpu):
     """K6+K7 fused on the oracle's own coarse weights: identical inputs -> the resampled depths and the merged, sorted
     fine depths equal the oracle's (the table is reproduced exactly; <= 1 ulp allowed for the interpolation)."""
