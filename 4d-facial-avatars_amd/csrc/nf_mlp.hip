@@ -534,7 +534,8 @@ extern "C" int nf_paper_mlp_fwd(const float* packed, const float* cond, const fl
 }
 
 // + one point tile of mask words: the exact-f32 masks are kept per 16-point tile, ceil(n / 16) of them per layer
-extern "C" size_t nf_paper_saved_floats(int64_t n_points) { return (size_t)nfl::SAVED_PER_POINT * (size_t)n_points + 9 * 128; }
+// (sized for the split training layout too: its sections are n_points rounded up to 32 points long, nf_mlp_bf16_machinery.inc)
+extern "C" size_t nf_paper_saved_floats(int64_t n_points) { return (size_t)nfl::SAVED_PER_POINT * (size_t)((n_points + 31) & ~(int64_t)31) + 9 * 128; }
 
 extern "C" int nf_paper_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd,
                                       const float* rd_view, const float* z, int64_t n_rays, int n_samples, float* raw,

@@ -20,6 +20,7 @@
 //       M(i-1)  2 + 2 fragment pairs per wave (conflict-free ds_read_b128), 12 MFMAs, branch-free.
 #include <cstdlib>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 // NFB_F16 = 1 (nf_mlp_f16_dw.hip includes this file): the same kernel on fp16 operand pairs.  Saved activations are converted
@@ -35,7 +36,7 @@
 #endif
 
 struct NfbDwSeg {
-    int kind;      // 0: dz section, 1: d_raw, 2: saved section
+    int kind;      // 0: dz section, 1: d_raw, 2: saved section in f32 rows (PE, dir slots), 3: saved section as (hi, lo) FRAGMENT STREAM
     int sec;       // section offset (floats per point)
     int width;     // floats per point
     int gs;        // kinds 0, 1: slot of the section's max |gradient| in the chain's table (fp16 instantiation)
@@ -63,6 +64,10 @@ struct NfbDwJob {
 #define NFB_DW_PTS 16                                    // points per stage = one MFMA k-step
 #define NFB_DW_NSET 3                                    // register sets of raw tiles: NSET - 1 stages of loads in flight
 #define NFB_DW_CVT_U4 (NFB_DW_MAX_TILES * 128)           // 16-byte units: per tile 64 lanes x (hi, lo)
+#define NFB_DW_RING 4                                    // fragment buffers: stage i lives in buffer i % 4 (a streamed tile is DMA'd two stages ahead)
+// K-slot j of lane half h of a 16-point stage <-> point 4 h + (j & 3) + 8 (j >> 2): the order in which the forward's transposing MFMA
+// leaves the points of a fragment block (NfbStreamSide).  Both operands of a product use it, so the sum over points is unchanged.
+__host__ __device__ constexpr int nfb_dw_point_of_slot(int h, int j) { return 4 * h + (j & 3) + 8 * (j >> 2); }
 static __constant__ NfbDwJob c_dwb_jobs[NFB_DW_JOBS];
 static __constant__ NfbDwJob c_dwb_jobs_lcode[NFB_DW_JOBS_LCODE];
 
@@ -82,7 +87,10 @@ struct NfbDwBuilder {
     }
     // segment + its tiles; cs >= 0: slab offset of the column sums of the section
     int add_seg(NfbDwJob& j, int kind, int sec, int width, int cs) {
-        j.seg[j.nseg] = NfbDwSeg{kind, sec, width, kind == 2 ? -1 : (kind == 1 ? 10 : slot_of(sec))};
+        // the split training forwards write every hidden layer's output (the 128- and 256-wide sections) as this kernel's operand
+        // fragments (nf_mlp_bf16_machinery.inc: NfbStreamSide); the positional encoding and the dir slots stay f32 rows
+        if (kind == 2 && width >= 128) kind = 3;
+        j.seg[j.nseg] = NfbDwSeg{kind, sec, width, kind >= 2 ? -1 : (kind == 1 ? 10 : slot_of(sec))};
         first_tile[j.nseg] = j.ntile;
         for (int f0 = 0; f0 < width; f0 += 32) j.tile[j.ntile++] = NfbDwTile{j.nseg, f0, cs >= 0 ? cs + f0 : -1};
         return j.nseg++;
@@ -231,8 +239,8 @@ __device__ __forceinline__ void nfb_dw_split_scaled(const float (&x)[8], float s
 }
 #endif
 
-// L step for one tile: lane (h, c) <- feature c of points p0 + 8 h .. + 7 (zero beyond the slice / the section width)
-// L step: raw buffer loads.  voff = this lane's byte offset of (point 8 h of the stage, its feature) within the slice's rows
+// L step for one f32-row tile: lane (h, c) <- feature c of points p0 + nfb_dw_point_of_slot(h, 0..7) (zero beyond the slice / the section width)
+// L step: raw buffer loads.  voff = this lane's byte offset of (point 4 h of the stage, its feature) within the slice's rows
 // of the section, or 0x80000000 for lanes past the section width; the 8 points are reached through the scalar offset
 // j * stride.  The hardware range check sees only voff (never the scalar offset), so the descriptor of the pipelined loop
 // covers exactly the WHOLE stages of the slice: they need no test, and stages past them (the pipeline overruns by a few)
@@ -240,14 +248,14 @@ __device__ __forceinline__ void nfb_dw_split_scaled(const float (&x)[8], float s
 __device__ __forceinline__ void nfb_dw_load(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned stride_b, float (&x)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(j * stride_b), 0));
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)voff, (int)(nfb_dw_point_of_slot(0, j) * stride_b), 0));
 }
 __device__ __forceinline__ void nfb_dw_load_tail(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned stride_b, int n_ok, int h,
                                                  float (&x)[8]) {
 #pragma unroll
     for (int j = 0; j < 8; ++j)
-        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(8 * h + j < n_ok ? voff : 0x80000000u),
-                                                                            (int)(j * stride_b), 0));
+        x[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(nfb_dw_point_of_slot(h, j) < n_ok ? voff : 0x80000000u),
+                                                                            (int)(nfb_dw_point_of_slot(0, j) * stride_b), 0));
 }
 
 // MODEL selects the job table: 0 paper model, 1 second model family
@@ -256,7 +264,7 @@ __global__ void __launch_bounds__(64 * NFB_DW_WAVES, 1)
 NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restrict__ d_raw, const float* __restrict__ saved,
                              int64_t n_points, int64_t pts_per_slice, float* __restrict__ slabs, int slab_floats,
                              const float* __restrict__ gscale) {
-    __shared__ __attribute__((aligned(16))) uint4 lds_cvt[2 * NFB_DW_CVT_U4];
+    __shared__ __attribute__((aligned(16))) uint4 lds_cvt[NFB_DW_RING * NFB_DW_CVT_U4];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int h = lane >> 5, c = lane & 31;
     const NfbDwJob& job = MODEL ? c_dwb_jobs_lcode[blockIdx.x] : c_dwb_jobs[blockIdx.x];
@@ -274,10 +282,18 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
     const NfbDwSeg tsg = job.seg[tl.seg];
     const bool t_fok = tl.f0 + c < tsg.width;
     const unsigned t_stride_b = 4u * (unsigned)tsg.width;
-    const float* t_g = (tsg.kind == 1 ? d_raw : (tsg.kind == 0 ? dz : saved) + (int64_t)tsg.sec * n_points) + p_begin * tsg.width;
-    const __amdgpu_buffer_rsrc_t t_rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(t_g), (short)0, (int)(n_stages * NFB_DW_PTS * t_stride_b), 0x00020000);
-    const unsigned t_voff = (t_on && t_fok) ? 4u * (unsigned)(tl.f0 + c) + (unsigned)(8 * h) * t_stride_b : 0x80000000u;
+    // sections of the split training forward's `saved` are n_pad = n_points rounded up to 32 points long
+    const int64_t n_pad = (n_points + 31) & ~(int64_t)31;
+    const bool t_stream = __builtin_amdgcn_readfirstlane((int)(t_on && tsg.kind == 3)) != 0;
+    const float* t_sec = tsg.kind == 1 ? d_raw : (tsg.kind == 0 ? dz + (int64_t)tsg.sec * n_points : saved + (int64_t)tsg.sec * n_pad);
+    const float* t_g = t_sec + p_begin * tsg.width;
+    const __amdgpu_buffer_rsrc_t t_rsrc = t_stream
+        ? __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t_sec), (short)0, (int)((unsigned)n_pad * t_stride_b), 0x00020000)   // the whole stream
+        : __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(t_g), (short)0, (int)(n_stages * NFB_DW_PTS * t_stride_b), 0x00020000);
+    const unsigned t_voff = (t_on && t_fok) ? 4u * (unsigned)(tl.f0 + c) + (unsigned)(4 * h) * t_stride_b : 0x80000000u;
+    // streamed tile: block pair of stage i = ((p_begin / 16 + i) * tiles of the section + tile) * 2 KiB, hi then lo, lane-linear
+    const unsigned s_blk0 = (unsigned)(p_begin >> 4) * (unsigned)(tsg.width >> 5) + (unsigned)(tl.f0 >> 5);
+    const unsigned s_step = (unsigned)(tsg.width >> 5);
     // Odd slices accumulate MINUS their gradient (the gradient operand is negated on the way into the MFMA, the slab entry on the
     // way out): the 16-bit-input MFMA accumulation is biased toward -inf by a fraction of an ulp per step, 700+ steps deep here,
     // and alternating the sign over slices lets that bias cancel in the slab reduction instead of adding up.
@@ -304,13 +320,27 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[t][u][r] = 0.f;
 
-    // One stage: M(i-1) out of fragment buffer (i+1)&1, C(i) into buffer i&1, L(i+2).  Always the full 2 x 2 block of
-    // MFMAs (narrower products simply do not store the surplus tiles).  The three MFMA groups (hi.hi, hi.lo, lo.hi; four
-    // independent accumulators each) are interleaved with the vector work of C and the loads of L so that one hides
-    // under the other; sched_barrier keeps the compiler from re-clustering them.
-    auto stage = [&](int i, const float (&xc)[8], float (&xn)[8]) {
-        const uint4* rd = lds_cvt + ((i + 1) & 1) * NFB_DW_CVT_U4 + lane;
-        uint4* wr = lds_cvt + (i & 1) * NFB_DW_CVT_U4 + wave * 128 + lane;
+    // One stage: M(i-1) out of fragment buffer (i-1) % 4; an f32-row tile: C(i) into buffer i % 4, L(i+2) into registers; a streamed
+    // tile: LDS-DMA of stage i+2's block pair into buffer (i+2) % 4 (free: last read by M(i-2), a barrier ago).  Always the full 2 x 2
+    // block of MFMAs (narrower products simply do not store the surplus tiles).  The three MFMA groups (hi.hi, hi.lo, lo.hi; four
+    // independent accumulators each) are interleaved with the vector work of C and the loads of L so that one hides under the
+    // other; sched_barrier keeps the compiler from re-clustering them.  The barrier is raw: __syncthreads() would drain the DMA.
+    auto dma = [&](int i) {                                 // this wave's block pair of stage i -> its tile's place in buffer i % 4
+        uint4* dst = lds_cvt + (i & (NFB_DW_RING - 1)) * NFB_DW_CVT_U4 + wave * 128;
+        const unsigned so = (s_blk0 + (unsigned)i * s_step) * 2048u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)(lane * 16), (int)so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)(dst + 64), 16, (int)(lane * 16), (int)(so + 1024u), 0, 0);
+    };
+    auto dma_into0 = [&](int i) {                           // the partial last stage: into buffer 0, outside the ring discipline
+        uint4* dst = lds_cvt + wave * 128;
+        const unsigned so = (s_blk0 + (unsigned)i * s_step) * 2048u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)dst, 16, (int)(lane * 16), (int)so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(t_rsrc, (__attribute__((address_space(3))) void*)(dst + 64), 16, (int)(lane * 16), (int)(so + 1024u), 0, 0);
+    };
+    auto stage = [&](auto stream_tag, int i, const float (&xc)[8], float (&xn)[8]) {
+        constexpr bool STREAM = decltype(stream_tag)::value;
+        const uint4* rd = lds_cvt + ((i + NFB_DW_RING - 1) & (NFB_DW_RING - 1)) * NFB_DW_CVT_U4 + lane;
+        uint4* wr = lds_cvt + (i & (NFB_DW_RING - 1)) * NFB_DW_CVT_U4 + wave * 128 + lane;
         bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -318,7 +348,7 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
             bh[t] = __builtin_bit_cast(bf16x8, rd[(pr.b_tile + t) * 128]);
         }
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if constexpr (!STREAM) {
             bf16x8 hi, lo;
 #if NFB_F16
             t_cs += ((xc[0] + xc[1]) + (xc[2] + xc[3])) + ((xc[4] + xc[5]) + (xc[6] + xc[7]));
@@ -332,6 +362,8 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
 #endif
             wr[0] = __builtin_bit_cast(uint4, hi);
             wr[64] = __builtin_bit_cast(uint4, lo);
+        } else {
+            dma(i + 2);
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -348,42 +380,62 @@ NFB_DW_NAME(k_paper_dw_gemm)(const float* __restrict__ dz, const float* __restri
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t) al[t] = __builtin_bit_cast(bf16x8, rd[(pr.a_tile + t) * 128 + 64]);
-        load(i + NFB_DW_NSET - 1, xn);
+        if constexpr (!STREAM) load(i + NFB_DW_NSET - 1, xn);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int u = 0; u < 2; ++u) acc[t][u] = NFB_MFMA(al[t], bh[u], acc[t][u], 0, 0, 0);
-        __syncthreads();
+        // this wave's fragment writes of stage i are done (f32-row tile) / its block pair of stage i has landed, the two later ones may fly
+        if constexpr (STREAM) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
     };
 
-    // the first M step (i = 0) reads fragment buffer 1 before anything was converted into it
-    for (int e = threadIdx.x; e < NFB_DW_CVT_U4; e += 64 * NFB_DW_WAVES) lds_cvt[NFB_DW_CVT_U4 + e] = make_uint4(0u, 0u, 0u, 0u);
+    // the first M step (i = 0) reads fragment buffer 3 before anything was written into it
+    for (int e = threadIdx.x; e < NFB_DW_CVT_U4; e += 64 * NFB_DW_WAVES) lds_cvt[(NFB_DW_RING - 1) * NFB_DW_CVT_U4 + e] = make_uint4(0u, 0u, 0u, 0u);
+    if (t_stream) {
+        dma(0);
+        dma(1);
+        __syncthreads();                                    // (drains the two DMAs: once, before the pipelined loop)
+        for (int i0 = 0; i0 <= n_stages; i0 += NFB_DW_NSET) {
 #pragma unroll
-    for (int q = 0; q < NFB_DW_NSET - 1; ++q) load(q, xs[q]);
-    __syncthreads();
-    for (int i0 = 0; i0 <= n_stages; i0 += NFB_DW_NSET) {
+            for (int q = 0; q < NFB_DW_NSET; ++q) stage(std::true_type{}, i0 + q, xs[q], xs[(q + NFB_DW_NSET - 1) % NFB_DW_NSET]);
+        }
+    } else {
 #pragma unroll
-        for (int q = 0; q < NFB_DW_NSET; ++q) stage(i0 + q, xs[q], xs[(q + NFB_DW_NSET - 1) % NFB_DW_NSET]);
+        for (int q = 0; q < NFB_DW_NSET - 1; ++q) load(q, xs[q]);
+        __syncthreads();
+        for (int i0 = 0; i0 <= n_stages; i0 += NFB_DW_NSET) {
+#pragma unroll
+            for (int q = 0; q < NFB_DW_NSET; ++q) stage(std::false_type{}, i0 + q, xs[q], xs[(q + NFB_DW_NSET - 1) % NFB_DW_NSET]);
+        }
     }
     if (n_tail > 0) {   // the partial stage (last slice only), not pipelined
-        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(t_g), (short)0, (int)((p_end - p_begin) * (int64_t)t_stride_b), 0x00020000);
-        float xt[8];
-        nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
-        bf16x8 hi, lo;
-#if NFB_F16
-        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
-        nfb_dw_split_scaled(xt, t_scale, hi, lo);
-#else
-        t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
-#pragma unroll
-        for (int j = 0; j < 8; ++j) xt[j] = __uint_as_float(__float_as_uint(xt[j]) ^ t_flip);
-        nfb_dw_split(xt, hi, lo);
-#endif
-        lds_cvt[wave * 128 + lane] = __builtin_bit_cast(uint4, hi);
-        lds_cvt[wave * 128 + lane + 64] = __builtin_bit_cast(uint4, lo);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (overrun DMAs of the loop target the ring: let them land before buffer 0 is reused)
         __syncthreads();
+        if (t_stream) {
+            dma_into0(n_stages);
+        } else {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<float*>(t_g), (short)0, (int)((p_end - p_begin) * (int64_t)t_stride_b), 0x00020000);
+            float xt[8];
+            nfb_dw_load_tail(rs, t_voff + (unsigned)n_stages * NFB_DW_PTS * t_stride_b, t_stride_b, n_tail, h, xt);
+            bf16x8 hi, lo;
+#if NFB_F16
+            t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
+            nfb_dw_split_scaled(xt, t_scale, hi, lo);
+#else
+            t_cs += ((xt[0] + xt[1]) + (xt[2] + xt[3])) + ((xt[4] + xt[5]) + (xt[6] + xt[7]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j) xt[j] = __uint_as_float(__float_as_uint(xt[j]) ^ t_flip);
+            nfb_dw_split(xt, hi, lo);
+#endif
+            lds_cvt[wave * 128 + lane] = __builtin_bit_cast(uint4, hi);
+            lds_cvt[wave * 128 + lane + 64] = __builtin_bit_cast(uint4, lo);
+        }
+        __syncthreads();                                    // (its fence also waits for the tail DMA)
         const uint4* rd = lds_cvt + lane;
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -457,6 +509,55 @@ int NFB_DW_NAME(nfb_launch_dw_gemm)(int model, const float* dz, const float* d_r
 }
 
 #if !NFB_F16
+
+// =================================================================================================
+// split training layout -> the exact-f32 training layout (tests, and the exact-f32 dW GEMMs run on a split forward's activations:
+// nf_*_mlp_bwd_bf16(..., exact_dw = 1)).  Stream sections: x = hi + lo (fp16 instantiation: / 2^4); f32-row sections and the bit
+// masks are copied from their n_pad-based places to the n-based places of nf_mlp_layout.h / nf_mlp_lcode_layout.h.
+// =================================================================================================
+__global__ void __launch_bounds__(256) k_unsplit_section(const unsigned short* __restrict__ stream, int64_t n_points, int width, int is_f16,
+                                                         float* __restrict__ out) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_points * width) return;
+    const int64_t p = e / width;
+    const int f = (int)(e - p * width), r = (int)(p & 15), h = (r >> 2) & 1, j = (r & 3) + 4 * (r >> 3), nt = f >> 5, c = f & 31;
+    const int64_t blk = ((p >> 4) * (width >> 5) + nt) * 2;                      // hi block; lo = + 1
+    const int idx = (h * 32 + c) * 8 + j;
+    const unsigned short bh = stream[blk * 512 + idx], bl = stream[(blk + 1) * 512 + idx];
+    float v;
+    if (is_f16) v = ((float)__builtin_bit_cast(_Float16, bh) + (float)__builtin_bit_cast(_Float16, bl)) * (1.0f / 16.0f);
+    else v = __uint_as_float((unsigned)bh << 16) + __uint_as_float((unsigned)bl << 16);
+    out[e] = v;
+}
+
+// model 0: paper, 1: second family.  out: nf_paper_saved_floats / nf_lcode_saved_floats(n_points) floats in the exact-f32 layout.
+extern "C" int nf_split_saved_to_f32(int model, const float* saved_split, int64_t n_points, int is_f16, float* out, nf_stream_t stream) {
+    if (!saved_split || !out || n_points <= 0 || (model != 0 && model != 1)) return NF_EINVAL;
+    const int64_t n = n_points, n_pad = (n + 31) & ~(int64_t)31;
+    struct Sec { int off, width, stream; };
+    static const Sec paper[] = {{nfl::S_PE, 64, 0}, {nfl::S_H0, 256, 1}, {nfl::S_H1, 256, 1}, {nfl::S_H2, 256, 1}, {nfl::S_H3, 256, 1},
+                                {nfl::S_H4, 256, 1}, {nfl::S_H5, 256, 1}, {nfl::S_FEAT, 256, 1}, {nfl::S_D0, 128, 1}, {nfl::S_D1, 128, 1},
+                                {nfl::S_D2, 128, 1}, {nfl::S_DIRF, 16, 0}, {nfl::S_MASK, 9 * 8, 0}};
+    static const Sec lcode[] = {{nlc::S_PE, 64, 0}, {nlc::S_L1, 256, 1}, {nlc::S_X0, 256, 1}, {nlc::S_X1, 256, 1}, {nlc::S_X2, 256, 1},
+                                {nlc::S_FEAT, 256, 1}, {nlc::S_DIR, 128, 1}, {nlc::S_DIRF, 16, 0}, {nlc::S_MASK, 5 * 8, 0}};
+    const Sec* secs = model ? lcode : paper;
+    const int n_secs = model ? (int)(sizeof(lcode) / sizeof(Sec)) : (int)(sizeof(paper) / sizeof(Sec));
+    for (int k = 0; k < n_secs; ++k) {
+        const Sec& sc = secs[k];
+        const float* src = saved_split + (int64_t)sc.off * n_pad;
+        float* dst = out + (int64_t)sc.off * n;
+        if (sc.stream) {
+            const int64_t total = n * sc.width, grid = (total + 255) / 256;
+            if (grid > 0x7fffffff) return NF_EINVAL;
+            hipLaunchKernelGGL(k_unsplit_section, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), reinterpret_cast<const unsigned short*>(src), n,
+                               sc.width, is_f16, dst);
+        } else {
+            const hipError_t e = hipMemcpyAsync(dst, src, (size_t)n * sc.width * sizeof(float), hipMemcpyDeviceToDevice, nf_s(stream));
+            if (e != hipSuccess) return (int)e;
+        }
+    }
+    NF_RETURN_LAUNCH();
+}
 
 // slices for the split-bf16 dW kernel: one workgroup per CU (paper: 11 bundles x 23 slices = 253 workgroups, second family:
 // 8 x 32 = 256); two rounds (46 slices) measured 2 % slower end to end (twice the slab traffic), three rounds slower still

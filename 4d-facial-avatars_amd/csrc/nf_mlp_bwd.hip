@@ -335,12 +335,15 @@ int nfb_launch_bwd_chain_f16(const void* packed_t, const float* saved, const flo
 // packed_t (exact f32 chain) | packed_t_bf16 (split-bf16 chain) | packed_t_f16 (split-fp16 chain + dW): exactly one non-NULL
 static int nf_bwd_impl(const float* packed, const float* packed_t, const void* packed_t_bf16, const void* packed_t_f16, bool split_dw,
                        const float* cond, const float* saved, const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
-                       size_t workspace_floats, float* grads, nf_stream_t stream, float* stage_ms = nullptr) {
+                       size_t workspace_floats, float* grads, nf_stream_t stream, float* stage_ms = nullptr, const float* saved_f32 = nullptr) {
+    // saved_f32: split chain + exact-f32 weight-gradient GEMMs only -- the split forward's activations converted to the exact-f32
+    // layout (nf_split_saved_to_f32); the chain reads its bit masks from `saved`, the GEMMs their operands from `saved_f32`
     using namespace nfl;
     if (!packed || (!packed_t && !packed_t_bf16 && !packed_t_f16) || !cond || !saved || !d_raw || !workspace || !grads || n_rays <= 0 ||
         n_samples <= 0)
         return NF_EINVAL;
     if (packed_t_f16) split_dw = true;
+    if ((packed_t_bf16 || packed_t_f16) && !split_dw && !saved_f32) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
     if (n_points >= ((int64_t)1 << 22)) return NF_EINVAL;                // as the training forward: 32-bit byte offsets into a dZ section
@@ -401,8 +404,8 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
                                      : nfb_launch_dw_gemm_bf16(0, dz, d_raw, saved, n_points, pps, ns, slabs, nullptr, stream);
         if (rc3) return rc3;
     } else {
-        hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(gset.first_block[NF_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz, d_raw, saved,
-                           n_points, slabs);
+        hipLaunchKernelGGL((k_dw_gemm_lds<0>), dim3(gset.first_block[NF_DW_GROUPS]), dim3(64 * NF_DW_WAVES), 0, s, gset, (int)SLAB_FLOATS, dz, d_raw,
+                           saved_f32 ? saved_f32 : saved, n_points, slabs);
     }
     mark(2);
     hipLaunchKernelGGL((k_grad_reduce<0>), dim3(512), dim3(256), 0, s, slabs, ns, (int)SLAB_FLOATS, sum, alt);
@@ -450,12 +453,13 @@ extern "C" int nf_paper_mlp_bwd(const float* packed, const float* packed_t, cons
 
 // Same, with the dX chain (nf_mlp_bf16_bwd.hip) and, unless exact_dw, the weight-gradient GEMMs (nf_mlp_bf16_dw.hip) on the
 // split-bf16 kernels.  `saved` must come from nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks the chain reads).
+// saved_f32 (exact_dw only, else NULL): `saved` converted by nf_split_saved_to_f32 -- the exact-f32 GEMMs read f32 rows.
 extern "C" int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
                                      const float* d_raw, int64_t n_rays, int n_samples, float* workspace, size_t workspace_floats,
-                                     float* grads, int exact_dw, nf_stream_t stream) {
-    if (!packed_t_bf16) return NF_EINVAL;
+                                     float* grads, int exact_dw, const float* saved_f32, nf_stream_t stream) {
+    if (!packed_t_bf16 || (exact_dw && !saved_f32)) return NF_EINVAL;
     return nf_bwd_impl(packed, nullptr, packed_t_bf16, nullptr, exact_dw == 0, cond, saved, d_raw, n_rays, n_samples, workspace,
-                       workspace_floats, grads, stream);
+                       workspace_floats, grads, stream, nullptr, exact_dw ? saved_f32 : nullptr);
 }
 
 // Same on fp16 operand pairs ("f16x3": fp32-class accuracy at the split-bf16 speed): dX chain (nf_mlp_f16_bwd.hip) and weight-

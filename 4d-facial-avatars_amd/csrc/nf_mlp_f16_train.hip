@@ -3,7 +3,7 @@
 // weight-gradient kernels read, plus the ReLU bit masks the split backward chain reads.
 #define NFB_F16 1
 #ifndef NFB_TILE_GROUP
-#define NFB_TILE_GROUP 4
+#define NFB_TILE_GROUP 2          // A fragments of 2 output tiles at a time: with the transposing side job of the saves, 4 spill 15 registers
 #endif
 #ifndef NFB_ACT_SHIFT
 #define NFB_ACT_SHIFT 4

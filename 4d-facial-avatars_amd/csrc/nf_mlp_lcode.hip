@@ -312,7 +312,8 @@ extern "C" int nf_lcode_mlp_fwd(const float* packed, const float* cond, const fl
 }
 
 // + one point tile of mask words (the exact-f32 masks are kept per 16-point tile)
-extern "C" size_t nf_lcode_saved_floats(int64_t n_points) { return (size_t)nlc::SAVED_PER_POINT * (size_t)n_points + 5 * 128; }
+// (sized for the split training layout too: its sections are n_points rounded up to 32 points long, nf_mlp_bf16_machinery.inc)
+extern "C" size_t nf_lcode_saved_floats(int64_t n_points) { return (size_t)nlc::SAVED_PER_POINT * (size_t)((n_points + 31) & ~(int64_t)31) + 5 * 128; }
 
 // Training forward: also fills `saved` (nf_lcode_saved_floats(n_points) floats), which nf_lcode_mlp_bwd reads.
 extern "C" int nf_lcode_mlp_fwd_train(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,

@@ -152,7 +152,7 @@ NFB_BWD_NAME(k_lcode_mlp_bwd_chain)(const char* __restrict__ wstream, const floa
     // ordinary loads first (d_raw, the five ReLU bit masks), then the ring
     const f32x4 d = reinterpret_cast<const f32x4*>(d_raw)[p];
     u32x4 mask[5];
-    const u32x4* mbase = reinterpret_cast<const u32x4*>(saved + (int64_t)S_MASK * n);
+    const u32x4* mbase = reinterpret_cast<const u32x4*>(saved + (int64_t)S_MASK * nfb_pad32(n));   // (split training layout: sections are n rounded up to 32 points long)
 #pragma unroll
     for (int l = 0; l < 5; ++l) mask[l] = mbase[((int64_t)l * n + p) * 2 + h];
     nfb_issue_w<nfb::stage_nblk(0)>(cx, nfb::stage_blk0(0), 0);

@@ -1,7 +1,7 @@
 // Training (activation-saving) instantiation of the split-fp16 forward of the second model family (cf. nf_mlp_f16_train.hip).
 #define NFB_F16 1
 #ifndef NFB_TILE_GROUP
-#define NFB_TILE_GROUP 4
+#define NFB_TILE_GROUP 2          // A fragments of 2 output tiles at a time: with the transposing side job of the saves, 4 spill 15 registers
 #endif
 #ifndef NFB_ACT_SHIFT
 #define NFB_ACT_SHIFT 4
@@ -10,7 +10,6 @@
 #include "nf_pack.h"
 
 #define NFB_SAVE 1
-#define NFB_LC_X2_EARLY 1          // see nf_mlp_lcode_bf16_kernel.inc
 #define NFB_KERNEL_NAME k_lcode_mlp_fwd_f16_train
 #include "nf_mlp_lcode_bf16_kernel.inc"
 

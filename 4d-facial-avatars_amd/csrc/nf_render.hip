@@ -542,7 +542,7 @@ __device__ __forceinline__ void nf_sort128_regs(float (&v)[2], int lane) {
 #pragma unroll
                 for (int r = 0; r < 2; ++r) {
                     const float o = __shfl_xor(v[r], j, 64);
-                    const bool lower = (lane & j) == 0, up = k == 128 ? true : ((lane & k) == 0);
+                    const bool lower = (lane & j) == 0, up = ((64 * r + lane) & k) == 0;      // (element index = 64 r + lane)
                     v[r] = (lower == up) ? fminf(v[r], o) : fmaxf(v[r], o);
                 }
             }

@@ -55,7 +55,8 @@ _PROTOTYPES = {
     "nf_paper_pack_bwd": (C.c_int, [_P, _P, _P]),
     "nf_paper_packed_bwd_bf16_bytes": (_Z, []),
     "nf_paper_pack_bwd_bf16": (C.c_int, [_P, _P, _P]),
-    "nf_paper_mlp_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _I, _P]),
+    "nf_paper_mlp_bwd_bf16": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _I, _P, _P]),
+    "nf_split_saved_to_f32": (C.c_int, [_I, _P, _L, _I, _P, _P]),
     "nf_paper_grad_floats": (_Z, []),
     "nf_paper_bwd_workspace_floats": (_Z, [_L]),
     "nf_paper_mlp_bwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),

@@ -407,6 +407,19 @@ def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None, pa
     return raw, (saved,)
 
 
+def split_saved_to_f32(saved_t: torch.Tensor, n_points: int, f16: bool, family: str = "paper") -> torch.Tensor:
+    """The activations a SPLIT training forward saved (fragment streams of (hi, lo) pairs, sections padded to 32 points) converted to
+    the exact-f32 training layout (sections [n_points][width] f32 rows at nfl::S_* x n_points): for tests and for the exact-f32
+    weight-gradient GEMMs on a split forward (paper_mlp_bwd(..., exact_dw=True))."""
+    dev = H.require_device(saved_t)
+    lib = H.lib()
+    out = torch.empty((lib.nf_lcode_saved_floats if family == "lcode" else lib.nf_paper_saved_floats)(n_points), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(lib.nf_split_saved_to_f32(1 if family == "lcode" else 0, H.ptr(saved_t), n_points, int(bool(f16)), H.ptr(out), H.stream_ptr(dev)),
+                "nf_split_saved_to_f32")
+    return out
+
+
 def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False, exact_dw=False):
     """d_raw (n_rays, n_samples, 4) -> ([26 parameter gradients in state_dict order], d_latent (32)).
     layers_dir.3.{weight,bias} get None, as autograd gives the reference (Quirk Q3).  split=True runs the dX chain on the
@@ -426,8 +439,10 @@ def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False, exact_dw=Fa
                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), H.stream_ptr(dev)), "nf_paper_mlp_bwd_f16")
         elif split:
             packed_bt = model.hip_weights().get_bf16_t()
+            saved_f32 = split_saved_to_f32(saved_t, n_rays * n_samples, False) if exact_dw else None      # the exact GEMMs read f32 rows
             H.check(lib.nf_paper_mlp_bwd_bf16(H.ptr(packed), H.ptr(packed_bt), H.ptr(cond), H.ptr(saved_t), H.ptr(d_raw), n_rays,
-                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), int(bool(exact_dw)), H.stream_ptr(dev)),
+                                              n_samples, H.ptr(ws), ws_floats, H.ptr(flat), int(bool(exact_dw)), H.ptr(saved_f32),
+                                              H.stream_ptr(dev)),
                     "nf_paper_mlp_bwd_bf16")
         else:
             packed_t = model.hip_weights().get_t()

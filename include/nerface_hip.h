@@ -163,13 +163,19 @@ int nf_paper_mlp_bwd_stage_ms(const float* packed, const void* packed_t_any, int
                               size_t workspace_floats, float* grads, float* stage_ms, nf_stream_t stream);
 
 /* Backward on the split-bf16 kernels: the dX chain and (unless exact_dw != 0) the weight-gradient GEMMs; bias/latent
- * reductions stay f32.  `saved` must have been written by nf_paper_mlp_fwd_train_bf16 (it carries the ReLU bit masks
- * the chain reads).                                                                                                  */
+ * reductions stay f32.  `saved` must have been written by nf_paper_mlp_fwd_train_bf16: the SPLIT TRAINING LAYOUT -- sections
+ * n_points rounded up to 32 points long; every hidden layer's output as the weight-gradient kernel's (hi, lo) operand fragments
+ * (csrc/nf_mlp_bf16_machinery.inc), positional encoding / dir slots as f32 rows, the ReLU bit masks the chain reads.
+ * exact_dw != 0 runs the exact-f32 GEMMs instead; they read f32 rows: saved_f32 = `saved` converted by nf_split_saved_to_f32
+ * (else NULL).
+ * nf_split_saved_to_f32: model 0 paper / 1 second family; is_f16 = the forward was the split-fp16 one; out = nf_paper_saved_floats /
+ * nf_lcode_saved_floats(n_points) floats in the exact-f32 training layout (x = hi + lo: 16 / 22 significand bits).        */
+int nf_split_saved_to_f32(int model, const float* saved_split, int64_t n_points, int is_f16, float* out, nf_stream_t stream);
 size_t nf_paper_packed_bwd_bf16_bytes(void);
 int nf_paper_pack_bwd_bf16(const float* const* params, void* packed_t_bf16, nf_stream_t stream);
 int nf_paper_mlp_bwd_bf16(const float* packed, const void* packed_t_bf16, const float* cond, const float* saved,
                           const float* d_raw, int64_t n_rays, int n_samples, float* workspace,
-                          size_t workspace_floats, float* grads, int exact_dw, nf_stream_t stream);
+                          size_t workspace_floats, float* grads, int exact_dw, const float* saved_f32, nf_stream_t stream);
 
 /* ---- K5: volume integrator -- replaces volume_render_radiance_field (V:7-75) + cumprod_exclusive
  *      (H:44-65) + the background overwrite of T:95-96 ----------------------------------------------- */

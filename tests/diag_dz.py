@@ -22,7 +22,8 @@ cond = ops.paper_condition(pk, c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O
 dv = lambda t: t.to(gpu)
 n_pts = n_rays * s
 _, saved = ops.paper_mlp_fwd_train(pk, cond, dv(ro), dv(rd), dv(z), packed_h=hw.get_f16())
-sv = saved[0]
+from tests.test_gpu_backward import f32_rows
+sv = f32_rows(saved[0], n_pts, "f16")
 masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
 # fp64 reference with hooks on the pre-activation gradients we care about
 pp = {k: v.to(gpu).double().clone().requires_grad_(True) for k, v in p.items()}

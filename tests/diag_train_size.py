@@ -25,7 +25,8 @@ for mode in ("f32", "f16", "bf16"):
     _, saved = ops.paper_mlp_fwd_train(pk, cond, dv(ro), dv(rd), dv(z), packed_b=hw.get_bf16() if mode == "bf16" else None,
                                        packed_h=hw.get_f16() if mode == "f16" else None)
     grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, dv(z), dv(d_raw), saved, split={"f32": False, "f16": "f16", "bf16": True}[mode])
-    sv = saved[0]
+    from tests.test_gpu_backward import f32_rows
+    sv = f32_rows(saved[0], n_pts, mode)
     masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
     pp = {k: v.to(gpu).double().clone().requires_grad_(True) for k, v in p.items()}
     lat = c["latent"].to(gpu).double().clone().requires_grad_(True)

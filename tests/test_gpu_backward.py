@@ -53,6 +53,35 @@ def saved_section(saved, name, n_points):
     return saved[off * n_points:(off + w) * n_points].view(n_points, w)
 
 
+def relu_masks(sv, n_points, mode):
+    """The nine ReLU decisions (RELU_ORDER) a training forward saved, as boolean (n_points, width) matrices.  Exact f32: the saved
+    post-ReLU activations are the f32 values themselves, x > 0.  Split forwards: the BIT MASKS their backward chain reads
+    (S_MASK: [layer][point][lane half h][4 dwords], bit 16 (nt & 1) + r of dword nt >> 1 <-> feature 32 nt + (r & 3) + 8 (r >> 2) + 4 h)
+    -- not the sign of the (hi, lo) pair, which is 0 for a positive activation below the pair's underflow (fp16: 1.9e-9)."""
+    if mode in ("f32", False, None):
+        return [saved_section(sv, k, n_points) > 0 for k in RELU_ORDER]
+    words = sv[2256 * n_points:(2256 + 72) * n_points].view(torch.int32).view(9, n_points, 2, 4)
+    out = []
+    for l, k in enumerate(RELU_ORDER):
+        width = SAVED[k][1]
+        m = torch.zeros((n_points, width), dtype=torch.bool, device=sv.device)
+        for nt in range(width // 32):
+            for h in range(2):
+                w = words[l, :, h, nt >> 1]
+                for r in range(16):
+                    m[:, 32 * nt + (r & 3) + 8 * (r >> 2) + 4 * h] = ((w >> (16 * (nt & 1) + r)) & 1).bool()
+        out.append(m)
+    return out
+
+
+def f32_rows(saved_t, n_points, mode):
+    """`saved` of a training forward in the exact-f32 layout the section table above describes.  The split forwards write their
+    hidden-layer outputs as the weight-gradient kernel's (hi, lo) fragment stream (csrc/nf_mlp_bf16_machinery.inc); the library's own
+    converter (nf_split_saved_to_f32: x = hi + lo) turns them back into f32 rows."""
+    from nerf import ops
+    return saved_t if mode in ("f32", False, None) else ops.split_saved_to_f32(saved_t, n_points, f16=mode in ("f16", "f16x3"))
+
+
 def _oracle_mlp_grads(p, ro, rd, z, expr, latent, d_raw, masks=None, dtype=torch.float64):
     pp = {k: v.to(dtype).clone().requires_grad_(True) for k, v in p.items()}
     lat = latent.to(dtype).clone().requires_grad_(True)
@@ -78,6 +107,7 @@ def test_bf16x3_training_forward_saves_match_f32(hip_lib, gpu, n_rays, s):
     raw_f, (sv_f,) = ops.paper_mlp_fwd_train(hw.get(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu))
     raw_b, (sv_b,) = ops.paper_mlp_fwd_train(hw.get(), cond, ro.to(gpu), rd.to(gpu), z.to(gpu), packed_b=hw.get_bf16())
     n_pts = n_rays * s
+    sv_b = f32_rows(sv_b, n_pts, "bf16")
     for name in SAVED:
         a, b = saved_section(sv_f.cpu(), name, n_pts), saved_section(sv_b.cpu(), name, n_pts)
         d = float((a - b).abs().max())
@@ -109,8 +139,8 @@ def test_paper_mlp_bwd(hip_lib, gpu, n_rays, s, split):
     # ReLU masks as the HIP forward saw them: the oracle's backward is evaluated with the same masks so that the
     # comparison measures the backward arithmetic, not the handful of units whose pre-activation rounds across 0
     n_pts = n_rays * s
-    sv = saved[0].cpu()
-    masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
+    sv = f32_rows(saved[0], n_pts, "bf16" if split else "f32").cpu()
+    masks = relu_masks(sv, n_pts, "bf16" if split else "f32")
     pp, lat, acts = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=masks)
     _, _, acts_free = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=None)
     order = RELU_ORDER[:6] + ["feat"] + RELU_ORDER[6:]
@@ -169,8 +199,8 @@ def test_paper_mlp_bwd_f16x3(hip_lib, gpu, n_rays, s):
             assert torch.equal(raw_t, ops.paper_mlp_fwd_f16(hw.get_f16(), cond, dv(ro), dv(rd), dv(z)))      # training forward == eval forward
         grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, dv(z), dv(d_raw), saved, split={"f32": False, "f16": "f16", "bf16": True}[mode])
         n_pts = n_rays * s
-        sv = saved[0].cpu()
-        masks = [saved_section(sv, k, n_pts) > 0 for k in RELU_ORDER]
+        sv = f32_rows(saved[0], n_pts, mode).cpu()
+        masks = relu_masks(sv, n_pts, mode)
         pp, lat, _ = _oracle_mlp_grads(p, ro, rd, z, c["expr"], c["latent"], d_raw, masks=masks)
         w = 0.0
         for k, gh in zip(ops.PAPER_KEYS, grads):
@@ -394,8 +424,9 @@ def test_training_kernels_vs_fp64_at_training_size(hip_lib, gpu, n_rays, s, spre
                                            packed_h=hw.get_f16() if mode == "f16" else None)
         grads, g_lat = ops.paper_mlp_bwd(m, pk, cond, dv(z), dv(d_raw), saved, split={"f32": False, "f16": "f16", "bf16": True}[mode])
         assert all(bool(torch.isfinite(x).all()) for x in grads if x is not None) and bool(torch.isfinite(g_lat).all())
-        masks = [saved_section(saved[0], k, n_pts) > 0 for k in RELU_ORDER]
-        saved_act[mode] = saved[0][:2256 * n_pts]
+        sv = f32_rows(saved[0], n_pts, mode)
+        masks = relu_masks(sv, n_pts, mode)
+        saved_act[mode] = sv[:2256 * n_pts]
         pp = {k: v.to(gpu).double().clone().requires_grad_(True) for k, v in p.items()}
         lat = c["latent"].to(gpu).double().clone().requires_grad_(True)
         out = O.paper_mlp(pp, x64, c["expr"].to(gpu).double(), lat, masks=masks)

@@ -92,7 +92,11 @@ def test_lcode_mlp_bwd_vs_fp64_oracle(hip_lib, gpu, n_rays, s, precision):
     assert torch.equal(raw_t, raw_e)                       # training forward == eval forward, bit for bit
     grads, g_lat = m.hip_backward(state, z.to(gpu), d_raw.to(gpu))
     n_pts = n_rays * s
-    sv = state[2].cpu()
+    sv = state[2]
+    if precision != "f32":         # the split forwards save fragment streams: the library's converter gives the f32 rows (x = hi + lo)
+        from nerf import ops
+        sv = ops.split_saved_to_f32(sv, n_pts, f16=precision == "f16x3", family="lcode")
+    sv = sv.cpu()
     sec = lambda k: sv[LC_SAVED[k][0] * n_pts:(LC_SAVED[k][0] + LC_SAVED[k][1]) * n_pts].view(n_pts, LC_SAVED[k][1])
 
     def oracle(masks):

@@ -7,6 +7,8 @@ import torch, bench, nerf
 dev = torch.device("cuda:0")
 precs = [a for a in sys.argv[1:] if a in ("f32", "bf16x3", "f16x3")] or ["bf16x3", "f16x3"]
 fams = ["paper"] + (["lcode"] if "lcode" in sys.argv[1:] else [])
+info = bench.device_info(dev)
+print(f"box: hbm_fill {info.get('hbm_fill_gbs', 0):.0f} GB/s, hbm_copy {info.get('hbm_copy_gbs', 0):.0f} GB/s", flush=True)
 for fam in fams:
     model = bench.synth_params(1, dev, fam).train()
     for prec in precs:
