@@ -26,9 +26,11 @@ On the same JSON line (every BASELINE config that fits this box is timed by this
   tiny         -- configs[0]: tiny_nerf 64x64x32 forward on the device next to the CPU oracle of the same image.
   eager_rocm   -- the reference algorithm as stock PyTorch-ROCm eager fp32 ops on the same GPU (bounded ray sample): the same-box
                   denominator BASELINE.md names next to the CPU one.
-  cpu_baseline -- the CPU oracle (port of the reference algorithm, oracle/nerface_oracle.py) timed on this box's host
-                  cores on a bounded sample of the same workload (rank 0, N=1 only); `reference_ratio` ties the port to the
-                  unmodified reference (both timed in the build container, profiles/r02_port_vs_reference_cpu.json).
+  cpu_baseline -- kind "reference": the UNMODIFIED reference's get_ray_bundle + run_one_iter_of_nerf (imported out of /root/reference, or
+                  out of oracle/_ref/nerface_ref.zip which oracle/make_ref.py packs and which travels with the push) timed on this box's
+                  host cores on a bounded sample of the same workload (rank 0, N=1 only), the oracle port beside it on a slice;
+                  kind "port" (labelled fallback) only where neither is present.
+  summary      -- LAST key of the line: flat scalars (the driver's record keeps only the tail of the line).
 """
 from __future__ import annotations
 
@@ -739,8 +741,7 @@ def pmc_traffic(precision, timeout=240):
 def pmc_train_traffic(train, timeout=300):
     """Fill `traffic` of every training kernel of the `train` object (all arithmetics in one pair of PMC passes).  The training
     kernels read with 16-byte lanes (dwordx4 / LDS-DMA), the access width for which MI355X_MICROARCH.md calibrates FETCH_SIZE at
-    half the bytes: `traffic` = 2 x fetch + write, the raw counters are kept beside it.  (The split weight-gradient kernels read
-    4 bytes per lane: raw.)"""
+    half the bytes: `traffic` = 2 x fetch + write, the raw counters are kept beside it."""
     precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
     names = [k for p in precs for k, _ in TRAIN_KERNELS[p]]
     got, detail = pmc_kernel_bytes("pmc_train_launch.py", precs, names, timeout)
@@ -750,10 +751,47 @@ def pmc_train_traffic(train, timeout=300):
                 obj["traffic_detail"] = detail
                 continue
             f, w = got[kname]["fetch_bytes"], got[kname]["write_bytes"]
-            wide = not kname.startswith("k_paper_dw_gemm_")
+            # (round 4: the split weight-gradient kernels DMA half of their operands 16 B per lane -- the forward's fragment stream -- and the
+            # raw FETCH_SIZE of the whole kernel is 0.55 of its algorithmic bytes: the x2 calibration applies to them as well)
+            wide = True
             obj["traffic"] = (2 * f if wide else f) + w
             obj["traffic_detail"] = {"fetch_bytes_raw": f, "write_bytes": w, "fetch_correction": "x2 (16 B/lane reads)" if wide else "none (4 B/lane reads)",
                                      "algorithmic_bytes_per_launch": obj["algorithmic_hbm_bytes_per_point"] * 2048 * 128, **detail}
+
+
+def pmc_train_clocks(train, timeout=300):
+    """Engine clock each training kernel actually held (GRBM_GUI_ACTIVE / dispatch time, one PMC pass over tools/pmc_train_launch.py in all
+    arithmetics) and its busy cycles: the split kernels (dense 16-bit MFMA + 9 KB/point of HBM traffic) are clocked down by the power
+    management to 1.55-2.1 GHz under sustained load (profiles/r04_experiments.md), so their wall time is cycles / granted clock --
+    `ms_at_nominal_clock` is what the same cycles take at the 2.4 GHz the peaks are quoted at."""
+    import shutil
+    import tempfile
+    precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
+    prof, why = _pmc_guard()
+    if prof is None or not precs:
+        return why
+    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
+    try:
+        rows, err = pmc_pass_rows(prof, tmp, "GRBM_GUI_ACTIVE", "pmc_train_launch.py", precs, timeout)
+        if rows is None:
+            return err
+        for p in precs:
+            for (kname, _), obj in zip(TRAIN_KERNELS[p], train[p]["roofline"]["kernels"]):
+                hits = [(v, d) for n, _, v, d in rows if kname in n and d]
+                if not hits:
+                    continue
+                div = 8 if sorted(v / (d * 1e-9) for v, d in hits)[len(hits) // 2] > 6e9 else 1
+                clk = sorted(v / div / (d * 1e-9) / 1e6 for v, d in hits)
+                cyc = sorted(v / div for v, _ in hits)[len(hits) // 2]
+                obj["sustained_clock_mhz"] = clk[len(clk) // 2]
+                obj["sustained_clock_mhz_range"] = [clk[0], clk[-1]]
+                obj["busy_mcycles"] = cyc / 1e6
+                obj["ms_at_nominal_clock"] = cyc / 2.4e9 * 1e3
+        return {"source": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE run by bench.py on tools/pmc_train_launch.py " + " ".join(precs)}
+    except Exception as e:
+        return {"error": repr(e)}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def main():
@@ -905,6 +943,7 @@ def main():
             line["train"] = train
             if world == 1:
                 pmc_train_traffic(train)
+                train["clock_detail"] = pmc_train_clocks(train)
 
     if rank == 0:
         # ---- roofline of the dominant kernel: fused MLP forward, fine pass of one ray chunk ----------------
@@ -963,6 +1002,10 @@ def main():
         if world == 1 and not args.no_extras:
             for prec in ("f32", "f16x3", "bf16x3"):
                 objs[prec]["traffic"], objs[prec]["traffic_detail"] = pmc_traffic(prec)
+            for prec in ("f16x3", "bf16x3"):
+                objs[prec]["sustained_clock_mhz"], objs[prec]["sustained_clock_detail"] = pmc_sustained_clock(prec)
+                if objs[prec]["sustained_clock_mhz"]:
+                    objs[prec]["frac_executed_at_sustained_clock"] = objs[prec]["frac_executed"] * 2400.0 / objs[prec]["sustained_clock_mhz"]
             mhz, clk_detail = pmc_sustained_clock("f32")
             objs["f32"]["sustained_clock_mhz"], objs["f32"]["sustained_clock_detail"] = mhz, clk_detail
             if mhz:
@@ -1019,6 +1062,8 @@ def summary_of(line):
          "split_f16_rays_s": g("split_f16", "value"), "split_bf16_rays_s": g("split_bf16", "value"),
          "split_f16_fine_launch_ms": g("split_f16", "roofline", "avg_launch_ms"),
          "split_bf16_fine_launch_ms": g("split_bf16", "roofline", "avg_launch_ms"),
+         "split_f16_clock_mhz": g("split_f16", "roofline", "sustained_clock_mhz"),
+         "split_bf16_clock_mhz": g("split_bf16", "roofline", "sustained_clock_mhz"),
          "split_f16_frac_executed": g("split_f16", "roofline", "frac_executed"),
          "split_bf16_frac_executed": g("split_bf16", "roofline", "frac_executed")}
     for prec in ("f32", "f16x3", "bf16x3"):
@@ -1027,6 +1072,8 @@ def summary_of(line):
         for tag, k in zip(("fwd_save", "chain", "dw"), ks):
             s[f"train_{prec}_{tag}_ms"] = k.get("avg_launch_ms")
             s[f"train_{prec}_{tag}_frac"] = k.get("frac")
+            s[f"train_{prec}_{tag}_clock_mhz"] = k.get("sustained_clock_mhz")
+            s[f"train_{prec}_{tag}_ms_at_2400mhz"] = k.get("ms_at_nominal_clock")
     ar = g("train", "allreduce") or {}
     s.update({"train_allreduce_us": ar.get("allreduce_us"), "train_bytes_allreduced": ar.get("bytes_allreduced"),
               "train_ranks_seen": ar.get("ranks_seen"),

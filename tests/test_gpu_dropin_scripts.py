@@ -86,10 +86,7 @@ def test_unmodified_scripts_run_against_the_product(hip_lib, gpu, tmp_path):
     for i in range(2):
         assert np.array_equal(_png(os.path.join(out2, f"{i:04d}.png")), _png(os.path.join(out, f"{i:04d}.png"))), i
         assert os.path.exists(os.path.join(out2, "normals", f"{i:04d}.png"))
-    # the straight path renders something else (own pose / expression per frame)
-    out3 = os.path.join(base, "render_straight")
-    eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out3])
-    assert not np.array_equal(_png(os.path.join(out3, "0000.png")), _png(os.path.join(out2, "0000.png")))
+    # (the straight path -- own pose / expression / latent row per frame -- is what tests/test_gpu_launchers.py renders)
 
 
 def test_launcher_as_shipped_equals_the_unmodified_eval_script_on_cpu(hip_lib, gpu, tmp_path):

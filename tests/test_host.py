@@ -337,26 +337,28 @@ def test_hot_kernels_keep_their_register_and_instruction_budget(tmp_path):
             found[name] = dict(lds=int(lds), scratch=int(scratch), vgpr=int(vgpr), spill=int(spill), body=body)
         return found
 
-    def one(ks, prefix):
-        hit = [v for k, v in ks.items() if k.startswith(prefix)]
-        assert len(hit) == 1, (prefix, sorted(ks))
+    def one(ks, name, tmpl):
+        """the kernel whose mangled name contains `name` and the template argument `tmpl` (no assumption about the mangling's digits)"""
+        hit = [v for k, v in ks.items() if re.search(r"\d+%s%s" % (re.escape(name), re.escape(tmpl)), k)]
+        assert len(hit) == 1, (name, tmpl, sorted(ks))
         return hit[0]
 
     ks = kernels("nf_mlp.hip")
-    for prefix in ("_Z15k_paper_mlp_fwdILi2E", "_Z20k_paper_mlp_fwd_saveILi2E"):
-        k = one(ks, prefix)
+    for prefix in ("k_paper_mlp_fwd", "k_paper_mlp_fwd_save"):
+        k = one(ks, prefix, "ILi2E")
         assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 512, (prefix, k["spill"], k["scratch"], k["vgpr"])
         assert k["lds"] == 131072                                        # four wave-private 32 KiB slabs: one workgroup per CU
         b = k["body"]
-        assert len(re.findall(r"v_mfma_f32_16x16x4_f32", b)) == 5000       # heads, loop bodies and tails of the 11 layers, NT = 2
+        n_mfma = len(re.findall(r"v_mfma_f32_16x16x4_f32", b))            # 999,936 MFMA FLOPs per point = 31248 MFMAs per 32-point wave tile, of
+        assert 3000 <= n_mfma <= 31248, n_mfma                           # which the K loops are rolled: 5000 static instructions in round 3/4 (a compiler may unroll differently)
         assert "flat_load" not in b and "s_barrier" not in b
         assert len(re.findall(r"buffer_load_dwordx4", b)) >= 600          # the weight and bias stream
         assert len(re.findall(r"global_load_dwordx4", b)) == 0            # (the round-2 form: a 64-bit vector address per fragment)
     ks = kernels("nf_mlp_bwd.hip")
-    k = one(ks, "_Z27k_paper_mlp_bwd_chain_masksILi2E")
+    k = one(ks, "k_paper_mlp_bwd_chain_masks", "ILi2E")
     assert k["spill"] == 0 and k["scratch"] == 0 and k["lds"] == 131072
     assert len(re.findall(r"buffer_load_dwordx4", k["body"])) >= 200
-    k = one(ks, "_Z13k_dw_gemm_ldsILi0E")
+    k = one(ks, "k_dw_gemm_lds", "ILi0E")
     assert k["spill"] == 0 and k["scratch"] == 0 and k["vgpr"] <= 256     # eight waves = two per SIMD
     assert len(re.findall(r"buffer_load_dwordx4 .* lds", k["body"])) >= 24 and "global_load_lds" not in k["body"]
 
@@ -371,10 +373,11 @@ def test_no_kernel_of_the_library_spills(hip_lib):
     if not all(os.path.exists(os.path.join(obj, u)) for u in units):
         build.build(force=True, verbose=False)               # objects cached from before the remarks were kept
     n = 0
+    sgpr_spills = {}
     for u in units:
         name = None
         for ln in open(os.path.join(obj, u)):
-            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill):\s+(\S+)", ln)
+            m = re.search(r"remark:\s+(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|VGPRs Spill|SGPRs Spill):\s+(\S+)", ln)
             if not m:
                 continue
             key, val = m.groups()
@@ -382,6 +385,15 @@ def test_no_kernel_of_the_library_spills(hip_lib):
                 name, n = val, n + 1
             elif key in ("ScratchSize [bytes/lane]", "VGPRs Spill"):
                 assert int(val) == 0, (u, name, key, val)
+            elif key == "SGPRs Spill":
+                # scalar spills go to VGPR lanes (v_writelane / v_readlane outside the K loops: descriptors and layer constants of the
+                # exact-f32 kernels), never to memory; reported, and bounded so that a regression shows (round 4: 38 in the
+                # headline kernel k_paper_mlp_fwd<2>, 29 in three training kernels, 0 in the other 77)
+                if int(val):
+                    sgpr_spills[name] = int(val)
+                assert int(val) <= 48, (u, name, key, val)
             elif key in ("VGPRs", "AGPRs"):
                 assert int(val) <= 512, (u, name, key, val)
     assert n >= 70, n                                           # 79 kernels in round 3
+    print("kernels with scalar-register spills (to VGPR lanes):", sgpr_spills)
+    assert len(sgpr_spills) <= 6, sgpr_spills
