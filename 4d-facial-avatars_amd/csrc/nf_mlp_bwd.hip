@@ -11,9 +11,11 @@
 //   B3  k_paper_grad_reduce /   sum the slabs over slices, then scatter into the 26 reference-layout tensors:
 //       k_paper_grad_unpack     PE slot order -> reference columns, folded conditioning columns as outer
 //                               products (db (x) [expr/3 | latent]), d latent = W[:,139:171]^T db.
+#include <cstdlib>
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
 #include "nf_mlp_dw.h"
 #include "nf_pack.h"
 
@@ -64,13 +66,15 @@ extern "C" int nf_paper_pack_bwd(const float* const* params, float* packed_t, nf
 // =================================================================================================
 // B1: backward chain
 // =================================================================================================
-// ReLU masks come from the bit masks the training forward left in section S_MASK (288 bytes per point, all nine layers fetched
-// at kernel entry) -- round 2 read 7.7 KB per point of saved activations synchronously at every layer boundary -- and every dZ
-// section leaves through the wave's LDS slab as whole lines, from inside the next layer's K loop (nf_mma_from_lds_copy, nf_mlp_dev.h).
+// The chain runs on the forward kernels' streamed K loops (nf_mlp_stream.h: nf_seg_lds, nf_tail_dz): C = 0 is the C operand of a layer's
+// first MFMAs, the copy of the slab to `dz` rides in the loops (whole lines through a range-checked descriptor), the layer boundary sits
+// under the last chunk's MFMAs with the ReLU mask applied on the way to the slab, and a layer's two mask words are fetched when its loop
+// starts.  Round 3's block epilogue (k_paper_mlp_bwd_chain_masks: 1.87 ms per 262144 points) against this form: 1.78-1.80 ms, every dZ
+// section and every gradient bit-identical (profiles/r04_experiments.md section 8).
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_paper_mlp_bwd_chain_masks(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
-                            int64_t n_points, float* __restrict__ dz) {
+                             int64_t n_points, float* __restrict__ dz) {
     using namespace nfl;
     static_assert(NT == 2, "the copy schedule below is written for 32-point slabs");
     __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
@@ -79,65 +83,69 @@ k_paper_mlp_bwd_chain_masks(const float* __restrict__ packed_t, const float* __r
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
     const int64_t n = n_points;
+    const NfW Wi = nf_w_image(packed_t, PACKED_T_FLOATS);
     auto sec = [&](int zs, int width) { return nf_slab_copy(dz, zs, width, p0, n); };
-
-    uint2 m[9][NT];                                   // layers h0..h5, layers_dir.0..2
-#pragma unroll
-    for (int l = 0; l < 9; ++l)
+    auto masks = [&](int l, uint2 (&m)[NT]) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            m[l][t] = p0 + 16 * t < n ? *nf_mask_ptr(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
-    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
+            m[t] = p0 + 16 * t < n ? *nf_mask_ptr(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
+    };
+    f32x4 frag_rgb[NT][1], frag_sig[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int64_t p = p0 + 16 * t + c;
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
         frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
-        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
+        frag_sig[t] = (f32x4){d.w, 0.f, 0.f, 0.f};
     }
     f32x4 acc[NT][16];
-#define NF_BWD_FINISH_M(NO_, MASKL_)                                                  \
-    do {                                                                              \
-        if ((MASKL_) >= 0) nf_apply_mask<NT, NO_>(acc, m[(MASKL_) < 0 ? 0 : (MASKL_)]); \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                \
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    uint64_t unused64[NT];
+    uint2 m[NT];
+#pragma unroll
+    for (int no = 0; no < 16; ++no) st.bias[no] = (f32x4){0.f, 0.f, 0.f, 0.f};      // C = 0: the C operand of every layer's first MFMAs
+    // d(layers_dir.2 out) = d rgb . fc_rgb.weight, masked by layers_dir.2's ReLU: one register chunk, the round-3 form
+    masks(8, m);
+    nf_zero_acc<NT, 8>(acc);
+    nf_mma_from_regs<NT, 8, 1>(acc, reinterpret_cast<const f32x4*>(packed_t) + OFFT_RGB / 4, frag_rgb, lane);
+    nf_apply_mask<NT, 8>(acc, m);
+    nf_store_act<NT, 8, false>(acc, act4, lane);
+    nf_load_w16<8>(st.wa, Wi, OFFT_D2 / 4, lane);
+    nf_read_b<NT>(st.b0, act4, lane, 0);
+    // one layer from the slab: the slab = dZ section ZSEC_ (W4_ float4 per row) is copied out and consumed; the output is masked by
+    // ReLU layer MASKL_ (-1: none) under the last chunk and becomes the next slab
+#define NF_CHAIN_LAYER(OFF_, NO_, NCH_, W4_, ZSEC_, MASKL_, OFF_NEXT_, NO_NEXT_)                                       \
+    do {                                                                                                             \
+        NfCopyH<W4_, 4, false> cs{act4, sec(ZSEC_, 4 * (W4_)), lane, (NCH_) / 2, {}};                                  \
+        cs.prime();                                                                                                  \
+        if ((MASKL_) >= 0) masks((MASKL_) >= 0 ? (MASKL_) : 0, m);                                                   \
+        nf_seg_lds<NT, NO_, true, false, false>(acc, st, Wi, OFF_, NCH_, act4, lane, cs, unused64);                  \
+        nf_pending_b<NT, false>(bj, st);                                                                             \
+        nf_tail_dz<NT, NO_, NO_NEXT_, ((MASKL_) >= 0)>(acc, st.wb, bj, st, Wi, OFF_NEXT_, act4, lane, m);            \
     } while (0)
-    // d(layers_dir.2 out) = d rgb . fc_rgb.weight ; mask by layers_dir.2's ReLU
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
-    NF_BWD_FINISH_M(8, 8);
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, WT + OFFT_D2 / 4, 8, act4, lane, sec(Z_D2, 128));
-    NF_BWD_FINISH_M(8, 7);
-    nf_zero_acc<NT, 8>(acc);
-    nf_mma_from_lds_copy<NT, 8, 32, 4>(acc, WT + OFFT_D1 / 4, 8, act4, lane, sec(Z_D1, 128));
-    NF_BWD_FINISH_M(8, 6);
-    // d feat = dZ_D0 . layers_dir.0.weight[:, :256] + d sigma * fc_alpha.weight   (no activation on feat)
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 32, 4>(acc, WT + OFFT_D0 / 4, 8, act4, lane, sec(Z_D0, 128));
-    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_D0 / 4 + 8 * 16 * 64, frag_sig, lane);
-    NF_BWD_FINISH_M(16, -1);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_FEAT / 4, 16, act4, lane, sec(Z_FEAT, 256));
-    NF_BWD_FINISH_M(16, 5);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L5 / 4, 16, act4, lane, sec(Z_L5, 256));
-    NF_BWD_FINISH_M(16, 4);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L4 / 4, 16, act4, lane, sec(Z_L4, 256));
-    NF_BWD_FINISH_M(16, 3);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L3 / 4, 16, act4, lane, sec(Z_L3, 256));     // hidden columns of the skip layer only
-    NF_BWD_FINISH_M(16, 2);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L2 / 4, 16, act4, lane, sec(Z_L2, 256));
-    NF_BWD_FINISH_M(16, 1);
-    nf_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_L1 / 4, 16, act4, lane, sec(Z_L1, 256));
-    NF_BWD_FINISH_M(16, 0);
-#undef NF_BWD_FINISH_M
+    NF_CHAIN_LAYER(OFFT_D2 / 4, 8, 8, 32, Z_D2, 7, OFFT_D1 / 4, 8);
+    NF_CHAIN_LAYER(OFFT_D1 / 4, 8, 8, 32, Z_D1, 6, OFFT_D0 / 4, 16);
+    // d feat = dZ_D0 . layers_dir.0.weight[:, :256] + d sigma * fc_alpha.weight   (no activation on feat): 8 slab chunks + one register chunk
+    {
+        f32x4 wd[16];
+        nf_load_w16<16>(wd, Wi, OFFT_D0 / 4 + 8 * 16 * 64, lane);          // the d-sigma chunk's weights, a layer ahead
+        NfCopyH<32, 4, false> cs{act4, sec(Z_D0, 128), lane, 4, {}};
+        cs.prime();
+        nf_seg_lds<NT, 16, true, false, false>(acc, st, Wi, OFFT_D0 / 4, 8, act4, lane, cs, unused64);
+        nf_pending_b<NT, false>(bj, st);
+        nf_chunk<NT, 16, false>(acc, st.wb, bj, st.bias);
+        nf_tail_dz<NT, 16, 16, false>(acc, wd, frag_sig, st, Wi, OFFT_FEAT / 4, act4, lane, m);
+    }
+    NF_CHAIN_LAYER(OFFT_FEAT / 4, 16, 16, 64, Z_FEAT, 5, OFFT_L5 / 4, 16);
+    NF_CHAIN_LAYER(OFFT_L5 / 4, 16, 16, 64, Z_L5, 4, OFFT_L4 / 4, 16);
+    NF_CHAIN_LAYER(OFFT_L4 / 4, 16, 16, 64, Z_L4, 3, OFFT_L3 / 4, 16);
+    NF_CHAIN_LAYER(OFFT_L3 / 4, 16, 16, 64, Z_L3, 2, OFFT_L2 / 4, 16);       // hidden columns of the skip layer only
+    NF_CHAIN_LAYER(OFFT_L2 / 4, 16, 16, 64, Z_L2, 1, OFFT_L1 / 4, 16);
+    NF_CHAIN_LAYER(OFFT_L1 / 4, 16, 16, 64, Z_L1, 0, 0, 0);
+#undef NF_CHAIN_LAYER
     {   // the last section has no K loop behind it
         const NfSlabCopy cp = sec(Z_L0, 256);
 #pragma unroll 4

@@ -9,6 +9,7 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
 #include "nf_mlp_lcode_layout.h"
 #include "nf_mlp_dw.h"
 #include "nf_pack.h"
@@ -58,8 +59,9 @@ __device__ __forceinline__ void nf_lc_zero_acc(f32x4 (&acc)[NT][16]) {
         for (int t = 0; t < NT; ++t) acc[t][no] = (f32x4){0.f, 0.f, 0.f, 0.f};
 }
 
-// ReLU masks from the bit masks the training forward left in section S_MASK (five layers, fetched at kernel entry); every dZ section
-// leaves through the wave's LDS slab as whole rows from inside the next layer's K loop (nf_mlp_dev.h; cf. k_paper_mlp_bwd_chain_masks).
+// Layer-streamed like the paper model's chain (nf_mlp_bwd.hip: k_paper_mlp_bwd_chain_masks; nf_mlp_stream.h: nf_seg_lds, nf_tail_dz):
+// C = 0 as the C operand of a layer's first MFMAs, the slab copied to `dz` from inside the K loops, the masked layer boundary under the
+// last chunk, a layer's two mask words fetched when its loop starts.
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restrict__ saved, const float* __restrict__ d_raw,
@@ -72,55 +74,65 @@ k_lcode_mlp_bwd_chain(const float* __restrict__ packed_t, const float* __restric
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* WT = reinterpret_cast<const f32x4*>(packed_t);
     const int64_t n = n_points;
+    const NfW Wi = nf_w_image(packed_t, PACKED_T);
     auto sec = [&](int zs, int width) { return nf_slab_copy(dz, zs, width, p0, n); };
-
-    uint2 m[5][NT];                                   // layers_xyz.0..2, fc_feat, layers_dir.0
-#pragma unroll
-    for (int l = 0; l < 5; ++l)
+    auto masks = [&](int l, uint2 (&m)[NT]) {           // layers_xyz.0..2 -> 0..2, fc_feat -> 3, layers_dir.0 -> 4
 #pragma unroll
         for (int t = 0; t < NT; ++t)
-            m[l][t] = p0 + 16 * t < n ? *nf_mask_ptr<S_MASK>(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
-    f32x4 frag_rgb[NT][1], frag_sig[NT][1];
+            m[t] = p0 + 16 * t < n ? *nf_mask_ptr<S_MASK>(const_cast<float*>(saved), n, l, (p0 >> 4) + t, lane) : make_uint2(0u, 0u);
+    };
+    f32x4 frag_rgb[NT][1], frag_sig[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int64_t p = p0 + 16 * t + c;
         f32x4 d = (f32x4){0.f, 0.f, 0.f, 0.f};
         if (p < n && g == 0) d = reinterpret_cast<const f32x4*>(d_raw)[p];
         frag_rgb[t][0] = (f32x4){d.x, d.y, d.z, 0.f};
-        frag_sig[t][0] = (f32x4){d.w, 0.f, 0.f, 0.f};
+        frag_sig[t] = (f32x4){d.w, 0.f, 0.f, 0.f};
     }
     f32x4 acc[NT][16];
-#define NF_LC_BWD_FINISH(NO_, MASKL_)                                                 \
-    do {                                                                              \
-        if ((MASKL_) >= 0) nf_apply_mask<NT, NO_>(acc, m[(MASKL_) < 0 ? 0 : (MASKL_)]); \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                \
-    } while (0)
-    // d(layers_dir.0 out) = d rgb . fc_rgb.weight, masked by its ReLU
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    uint64_t unused64[NT];
+    uint2 m[NT];
+#pragma unroll
+    for (int no = 0; no < 16; ++no) st.bias[no] = (f32x4){0.f, 0.f, 0.f, 0.f};      // C = 0
+    // d(layers_dir.0 out) = d rgb . fc_rgb.weight, masked by its ReLU: one register chunk, the round-3 form
+    masks(4, m);
     nf_lc_zero_acc<NT, 8>(acc);
-    nf_mma_from_regs<NT, 8, 1>(acc, WT + OFFT_RGB / 4, frag_rgb, lane);
-    NF_LC_BWD_FINISH(8, 4);
+    nf_mma_from_regs<NT, 8, 1>(acc, reinterpret_cast<const f32x4*>(packed_t) + OFFT_RGB / 4, frag_rgb, lane);
+    nf_apply_mask<NT, 8>(acc, m);
+    nf_store_act<NT, 8, false>(acc, act4, lane);
+    nf_load_w16<16>(st.wa, Wi, OFFT_DIR / 4, lane);
+    nf_read_b<NT>(st.b0, act4, lane, 0);
+#define NF_LC_CHAIN_LAYER(OFF_, NCH_, W4_, ZSEC_, MASKL_, OFF_NEXT_, NO_NEXT_)                                         \
+    do {                                                                                                             \
+        NfCopyH<W4_, 4, false> cs{act4, sec(ZSEC_, 4 * (W4_)), lane, (NCH_) / 2, {}};                                  \
+        cs.prime();                                                                                                  \
+        if ((MASKL_) >= 0) masks((MASKL_) >= 0 ? (MASKL_) : 0, m);                                                   \
+        nf_seg_lds<NT, 16, true, false, false>(acc, st, Wi, OFF_, NCH_, act4, lane, cs, unused64);                   \
+        nf_pending_b<NT, false>(bj, st);                                                                             \
+        nf_tail_dz<NT, 16, NO_NEXT_, ((MASKL_) >= 0)>(acc, st.wb, bj, st, Wi, OFF_NEXT_, act4, lane, m);             \
+    } while (0)
     // d feat = dZ_dir . layers_dir.0.weight[:, :256], masked by relu(fc_feat)
-    nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 32, 4>(acc, WT + OFFT_DIR / 4, 8, act4, lane, sec(Z_DIR, 128));
-    NF_LC_BWD_FINISH(16, 3);
-    // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight, masked by layers_xyz.2's ReLU
-    nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_FEAT / 4, 16, act4, lane, sec(Z_FEAT, 256));
-    nf_mma_from_regs<NT, 16, 1>(acc, WT + OFFT_FEAT / 4 + 16 * 16 * 64, frag_sig, lane);
-    NF_LC_BWD_FINISH(16, 2);
-    nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X2 / 4, 16, act4, lane, sec(Z_X2, 256));
-    NF_LC_BWD_FINISH(16, 1);
-    nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X1 / 4, 16, act4, lane, sec(Z_X1, 256));
-    NF_LC_BWD_FINISH(16, 0);
-    // d(layer1 out): layer1 has no activation (M:609)
-    nf_lc_zero_acc<NT, 16>(acc);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, WT + OFFT_X0 / 4, 16, act4, lane, sec(Z_X0, 256));
-    NF_LC_BWD_FINISH(16, -1);
-#undef NF_LC_BWD_FINISH
+    NF_LC_CHAIN_LAYER(OFFT_DIR / 4, 8, 32, Z_DIR, 3, OFFT_FEAT / 4, 16);
+    // d x2 = dZ_feat . fc_feat.weight + d sigma * fc_alpha.weight, masked by layers_xyz.2's ReLU: 16 slab chunks + one register chunk
+    {
+        f32x4 wd[16];
+        nf_load_w16<16>(wd, Wi, OFFT_FEAT / 4 + 16 * 16 * 64, lane);
+        NfCopyH<64, 4, false> cs{act4, sec(Z_FEAT, 256), lane, 8, {}};
+        cs.prime();
+        masks(2, m);
+        nf_seg_lds<NT, 16, true, false, false>(acc, st, Wi, OFFT_FEAT / 4, 16, act4, lane, cs, unused64);
+        nf_pending_b<NT, false>(bj, st);
+        nf_chunk<NT, 16, false>(acc, st.wb, bj, st.bias);
+        nf_tail_dz<NT, 16, 16, true>(acc, wd, frag_sig, st, Wi, OFFT_X2 / 4, act4, lane, m);
+    }
+    NF_LC_CHAIN_LAYER(OFFT_X2 / 4, 16, 64, Z_X2, 1, OFFT_X1 / 4, 16);
+    NF_LC_CHAIN_LAYER(OFFT_X1 / 4, 16, 64, Z_X1, 0, OFFT_X0 / 4, 16);
+    NF_LC_CHAIN_LAYER(OFFT_X0 / 4, 16, 64, Z_X0, -1, 0, 0);              // d(layer1 out): layer1 has no activation (M:609)
+#undef NF_LC_CHAIN_LAYER
     {   // the last section has no K loop behind it
         const NfSlabCopy cp = sec(Z_L1, 256);
 #pragma unroll 4

@@ -271,3 +271,68 @@ __device__ __forceinline__ void nf_tail(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
         for (int t = 0; t < NT; ++t) st.b0[t] = braw[t];
     }
 }
+
+// ---- the backward chains' layer boundary (round 4) ----------------------------------------------------------------------------
+// Round 3's dX chains ended every layer with a block of non-matrix work per wave (128 v_accvgpr_read, the mask arithmetic, 32 ds_write,
+// 128 v_accvgpr_write to zero the accumulators, the first loads of the next layer) during which the matrix pipe of the SIMD idles.
+// nf_tail_dz is nf_tail for them: the last K chunk with every tile written to the slab two tiles behind its last MFMA -- MASKED on the
+// way (dZ needs writer-side masks: the row-wise copy of the slab to `dz` is done by other lanes than the ones that own the mask bits) --
+// and the next layer's first weight chunk and B fragment requested underneath.  The chains pass zeros as st.bias: C = 0 is the C operand
+// of a layer's first MFMAs (no accumulator initialisation).
+template <int NT, int NO, int NO_NEXT, bool MASKED>
+__device__ __forceinline__ void nf_tail_dz(f32x4 (&acc)[NT][16], const f32x4 (&w)[16], const f32x4 (&b)[NT], NfStream<NT>& st, const NfW& W,
+                                           unsigned wnext, f32x4* act4, int lane, const uint2 (&m)[NT]) {
+    constexpr int LAG = NF_TAIL_LAG;
+    constexpr int NL = NO_NEXT;                                        // prefetch loads (weights only), spread over the NO tile steps
+    const int g = lane >> 4, c = lane & 15;
+    __builtin_amdgcn_sched_barrier(0);
+    if (NO_NEXT > 0) nf_load_w16<(NO_NEXT > 0 ? NO_NEXT : 1)>(st.wa, W, wnext, lane);
+    f32x4 braw[NT];
+#pragma unroll
+    for (int no = 0; no < NO + LAG; ++no) {
+        if (no < NO) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t][no] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[no][r], b[t][r], acc[t][no], 0, 0, 0);
+        }
+        if (no >= LAG) {
+            const int q = no - LAG;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 v = acc[t][q];
+                if (MASKED) {
+                    const uint32_t wd = q < 8 ? m[t].x : m[t].y;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int keep = ((int)(wd << (31 - (4 * (q & 7) + r)))) >> 31;      // v_bfe_i32: 0 or -1
+                        v[r] = __int_as_float(__float_as_int(v[r]) & keep);
+                    }
+                }
+                act4[nf_act_idx4(16 * t + c, 4 * q + g)] = v;
+            }
+        }
+        if (no == LAG && NO_NEXT > 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) braw[t] = act4[nf_act_idx4(16 * t + c, g)];
+        }
+    }
+#pragma unroll
+    for (int no = 0; no < NO + LAG; ++no) {
+        if (no < NO) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
+            NF_SGB_N(0x020, (no + 1) * NL / NO - no * NL / NO);
+        }
+        if (no >= LAG) {
+            __builtin_amdgcn_sched_group_barrier(0x002, (MASKED ? 12 : 4) * NT, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, NT, 0);
+        }
+        if (no == LAG && NO_NEXT > 0) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (NO_NEXT > 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) st.b0[t] = braw[t];
+    }
+}
+
