@@ -282,7 +282,7 @@ __device__ __forceinline__ void nf_tail(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
 template <int NT, int NO, int NO_NEXT, bool MASKED>
 __device__ __forceinline__ void nf_tail_dz(f32x4 (&acc)[NT][16], const f32x4 (&w)[16], const f32x4 (&b)[NT], NfStream<NT>& st, const NfW& W,
                                            unsigned wnext, f32x4* act4, int lane, const uint2 (&m)[NT]) {
-    constexpr int LAG = NF_TAIL_LAG;
+    constexpr int LAG = NF_TAIL_LAG;                                   // (lags 1, 3, 4 and no VALU group hint: all within noise, profiles/r04_experiments.md section 8)
     constexpr int NL = NO_NEXT;                                        // prefetch loads (weights only), spread over the NO tile steps
     const int g = lane >> 4, c = lane & 15;
     __builtin_amdgcn_sched_barrier(0);
