@@ -119,7 +119,6 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
     f32x4 pe[NT][4];
     f32x4 dirf[NT][1];
 #pragma unroll
@@ -197,8 +196,8 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
 }
 
 // Training forward (exact f32): the same arithmetic plus `saved` (layout nlc::S_*) -- every layer output as whole rows out of the
-// wave's LDS slab from inside the next layer's K loop, ReLU bit masks beside them (nf_mlp_dev.h; the paper model's
-// k_paper_mlp_fwd_save is the template).  layers_xyz.2's output is read by fc_alpha AND fc_feat: it is copied under fc_feat's loop.
+// wave's LDS slab from inside the next layer's K loop, ReLU bit masks beside them (nf_mlp_dev.h, nf_mlp_stream.h; the paper model's
+// k_paper_mlp_fwd_save is the template).
 template <int NT>
 __global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
 k_lcode_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ ro,
@@ -212,7 +211,6 @@ k_lcode_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
     const int64_t n = n_points;
     auto sec = [&](int s_, int width) { return nf_slab_copy(saved, s_, width, p0, n); };
     f32x4 pe[NT][4];
@@ -239,44 +237,92 @@ k_lcode_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
 #pragma unroll
         for (int k = 0; k < 16 * NT / 4; ++k) nf_copy_rows<16>(act4, cp, k, lane);
     }
+    // Layer-streamed like k_paper_mlp_fwd_save (nf_mlp.hip) and this family's inference kernel above: bias as the C operand, the layer
+    // boundary under the last chunk's MFMAs (raw accumulators to the slab), the next layer prefetched; what the backward needs is produced
+    // where the slab is READ -- the loop that consumes a layer's output applies the ReLU to its B fragments, collects their [x > 0] bits
+    // and carries the copy of the slab to `saved`.  layers_xyz.2's output is read twice (fc_alpha, fc_feat): copied and masked under fc_feat.
     f32x4 acc[NT][16];
-    uint2 m[NT];
-#define NF_LC_FINISH_SAVE(NO_, MASKL_)                                                                   \
-    do {                                                                                                \
-        if ((MASKL_) >= 0) {                                                                            \
-            nf_relu_with_mask<NT, NO_>(acc, m);                                                         \
-            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                              \
-                if (p0 + 16 * t < n) *nf_mask_ptr<S_MASK>(saved, n, MASKL_, (p0 >> 4) + t, lane) = m[t]; \
-        }                                                                                               \
-        nf_store_act<NT, NO_, false>(acc, act4, lane);                                                  \
-    } while (0)
-    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);                         // layer1: no activation (M:609)
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L1 / 4, pe, lane);
-    NF_LC_FINISH_SAVE(16, -1);
-    nf_init_acc<NT, 16>(acc, cond + B_X0, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X0 / 4, 16, act4, lane, sec(S_L1, 256));
-    NF_LC_FINISH_SAVE(16, 0);
-    nf_init_acc<NT, 16>(acc, cond + B_X1, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X1 / 4, 16, act4, lane, sec(S_X0, 256));
-    NF_LC_FINISH_SAVE(16, 1);
-    nf_init_acc<NT, 16>(acc, cond + B_X2, lane);
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_X2 / 4, 16, act4, lane, sec(S_X1, 256));
-    NF_LC_FINISH_SAVE(16, 2);
-    nf_init_acc<NT, 1>(acc, cond + B_ALPHA, lane);                       // fc_alpha(x)
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_ALPHA / 4, 16, act4, lane);
+    uint64_t m64[NT];
+    NfStream<NT> st;
+    f32x4 bj[NT];
     float sigma_raw[NT];
+    const NfW Wi = nf_w_image(packed, PACKED), Ci = nf_w_image(cond, COND_FLOATS);
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    // the last chunk's fragment (+ its mask bits), then the finished mask words of ReLU layer MASKL_ (the layer whose output was just consumed)
+#define NF_LC_PENDING(RELU_, MASKL_, NCH_)                                                          \
+    do {                                                                                            \
+        nf_pending_b<NT, RELU_>(bj, st);                                                            \
+        if ((MASKL_) >= 0) {                                                                        \
+            nf_mask_bits<NT>(m64, st.bp, (NCH_) - 2);                                               \
+            nf_mask_bits<NT>(m64, bj, (NCH_) - 1);                                                  \
+            _Pragma("unroll") for (int t = 0; t < NT; ++t)                                          \
+                if (p0 + 16 * t < n)                                                                \
+                    *nf_mask_ptr<S_MASK>(saved, n, (MASKL_) >= 0 ? (MASKL_) : 0, (p0 >> 4) + t, lane) = make_uint2((uint32_t)m64[t], (uint32_t)(m64[t] >> 32)); \
+        }                                                                                           \
+    } while (0)
+    // one 256-wide layer from the slab: the slab = section SEC_ (ReLU layer MASKL_, or -1: as stored) is copied out and consumed
+#define NF_LC_LAYER256(OFF_, SEC_, MASKL_, OFF_NEXT_, B_NEXT_, NO_NEXT_)                                                   \
+    do {                                                                                                                   \
+        NfCopyH<64, 4, ((MASKL_) >= 0)> cs{act4, sec(SEC_, 256), lane, 8, {}};                                             \
+        cs.prime();                                                                                                        \
+        _Pragma("unroll") for (int t = 0; t < NT; ++t) m64[t] = 0;                                                         \
+        nf_seg_lds<NT, 16, true, ((MASKL_) >= 0), ((MASKL_) >= 0)>(acc, st, Wi, OFF_, 16, act4, lane, cs, m64);            \
+        NF_LC_PENDING(((MASKL_) >= 0), MASKL_, 16);                                                                        \
+        nf_tail<NT, 16, 16, NO_NEXT_, 1>(acc, st.wb, bj, st, Wi, OFF_NEXT_, Ci, B_NEXT_, act4, lane);                     \
+    } while (0)
+    // ---- layer1 : PE(64 slots) -> 256, no activation (M:609) ---------------------------------------------------------
+    nf_load_bias<16>(st.bias, Ci, B_L1, lane);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_X0 / 4, Ci, B_X0, act4, lane);
+    }
+    // ---- layers_xyz.0 (reads layer1's output as stored), .1, .2 ---------------------------------------------------------
+    NF_LC_LAYER256(OFF_X0 / 4, S_L1, -1, OFF_X1 / 4, B_X1, 16);
+    NF_LC_LAYER256(OFF_X1 / 4, S_X0, 0, OFF_X2 / 4, B_X2, 16);
+    NF_LC_LAYER256(OFF_X2 / 4, S_X1, 1, OFF_ALPHA / 4, B_ALPHA, 1);
+    // ---- fc_alpha(x2): one tile, stores nothing (the slab stays for fc_feat), copies nothing -------------------------------
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_ALPHA / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 1, 0, 16, 1>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
 #pragma unroll
     for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
-    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);                       // feat = relu(fc_feat(x))
-    nf_mma_from_lds_copy<NT, 16, 64, 4>(acc, W + OFF_FEAT / 4, 16, act4, lane, sec(S_X2, 256));
-    NF_LC_FINISH_SAVE(16, 3);
-    nf_init_acc<NT, 8>(acc, cond + B_DIR, lane);                         // relu(layers_dir.0([feat | dir]))
-    nf_mma_from_lds_copy<NT, 8, 64, 4>(acc, W + OFF_DIR / 4, 16, act4, lane, sec(S_FEAT, 256));
-    nf_mma_from_regs<NT, 8, 1>(acc, W + OFF_DIR / 4 + 16 * 8 * 64, dirf, lane);
-    NF_LC_FINISH_SAVE(8, 4);
-#undef NF_LC_FINISH_SAVE
-    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
-    nf_mma_from_lds_copy<NT, 1, 32, 4>(acc, W + OFF_RGB / 4, 8, act4, lane, sec(S_DIR, 128));
+    // ---- feat = relu(fc_feat(x2)): x2 is copied and its mask collected here ---------------------------------------------
+    NF_LC_LAYER256(OFF_FEAT / 4, S_X2, 2, OFF_DIR / 4, B_DIR, 8);
+    // ---- layers_dir.0 : [feat | dir slots] -> 128 ---------------------------------------------------------------------------
+    {
+        f32x4 wd[16];
+        nf_load_w16<8>(wd, Wi, OFF_DIR / 4 + 16 * 8 * 64, lane);             // the dir-slot chunk's weights, a layer ahead
+        NfCopyH<64, 4, true> cs{act4, sec(S_FEAT, 256), lane, 8, {}};
+        cs.prime();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m64[t] = 0;
+        nf_seg_lds<NT, 8, true, true, true>(acc, st, Wi, OFF_DIR / 4, 16, act4, lane, cs, m64);
+        NF_LC_PENDING(true, 3, 16);
+        nf_chunk<NT, 8, false>(acc, st.wb, bj, st.bias);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_tail<NT, 8, 8, 1, 1>(acc, wd, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    }
+    // ---- fc_rgb (128-wide rows: two per copy instruction) ---------------------------------------------------------------------
+    {
+        NfCopyH<32, 4, true> cs{act4, sec(S_DIR, 128), lane, 4, {}};
+        cs.prime();
+#pragma unroll
+        for (int t = 0; t < NT; ++t) m64[t] = 0;
+        nf_seg_lds<NT, 1, true, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane, cs, m64);
+        NF_LC_PENDING(true, 4, 8);
+        nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
+    }
+#undef NF_LC_LAYER256
+#undef NF_LC_PENDING
+#undef NF_PE_B
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
