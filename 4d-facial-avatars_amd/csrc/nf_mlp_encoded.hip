@@ -2,6 +2,7 @@
 // run_network, nerf/train_utils.py:20-24): x (P, 87) = [PE10(xyz) (63) | PE4(dirs) (24)] -> (P, 4).  Inference only; the
 // hot path (run_one_iter_of_nerf) never materialises x and uses nf_paper_mlp_fwd instead.  Own translation unit on purpose.
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
 
 // bias table without the direction fold: the 24 direction columns arrive with x
 __global__ void __launch_bounds__(256) k_paper_condition_encoded(const float* __restrict__ packed, const float* __restrict__ expr,
@@ -38,7 +39,6 @@ k_paper_mlp_fwd_encoded(const float* __restrict__ packed, const float* __restric
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
     f32x4 pe[NT][4];
     f32x4 dirf[NT][2];
 #pragma unroll
@@ -67,44 +67,80 @@ k_paper_mlp_fwd_encoded(const float* __restrict__ packed, const float* __restric
             dirf[t][j] = (f32x4){v[0], v[1], v[2], v[3]};
         }
     }
+    // Layer-streamed form, as k_paper_mlp_fwd (nf_mlp_stream.h): raw accumulators to the slab under the last K chunk, the bias as the C
+    // operand of a layer's first MFMAs, the ReLU where the slab is read.  Differences: the inputs came from x87 above, and layers_dir.0
+    // takes its 24 direction columns as two register chunks (weights OFF_D0E: 16 feature chunks, then 2 direction chunks of 9 tiles).
     f32x4 acc[NT][16];
-    nf_init_acc<NT, 16>(acc, cond + B_L0, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L0 / 4, pe, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_L1, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L1 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_L2, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L2 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_L3, lane);
-    nf_mma_from_regs<NT, 16, 4>(acc, W + OFF_L3 / 4, pe, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_L4, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L4 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_L5, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_L5 / 4, 16, act4, lane);
-    nf_store_act<NT, 16, true>(acc, act4, lane);
-    nf_init_acc<NT, 16>(acc, cond + B_FEAT, lane);
-    nf_mma_from_lds<NT, 16>(acc, W + OFF_FEAT / 4, 16, act4, lane);
-    nf_store_act<NT, 16, false>(acc, act4, lane);
-    nf_init_acc<NT, 9>(acc, cond + B_D0, lane);
-    nf_mma_from_lds<NT, 9>(acc, W + OFF_D0E / 4, 16, act4, lane);
-    nf_mma_from_regs<NT, 9, 2>(acc, W + OFF_D0E / 4 + 16 * 9 * 64, dirf, lane);
+    NfStream<NT> st;
+    const NfW Wi = nf_w_image(packed, PACKED_FLOATS), Ci = nf_w_image(cond, COND_FLOATS);
+    f32x4 bj[NT];
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    nf_load_bias<16>(st.bias, Ci, B_L0, lane);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_L1 / 4, Ci, B_L1, act4, lane);
+    }
+#define NF_ENC_LAYER256(OFF_, OFF_NEXT_, B_NEXT_, NO_NEXT_, NEXT_B_)                                                        \
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, (OFF_) / 4, 16, act4, lane);                                                \
+    nf_pending_b<NT, true>(bj, st);                                                                                         \
+    nf_tail<NT, 16, 16, NO_NEXT_, NEXT_B_>(acc, st.wb, bj, st, Wi, (OFF_NEXT_) / 4, Ci, B_NEXT_, act4, lane)
+    NF_ENC_LAYER256(OFF_L1, OFF_L2, B_L2, 16, 1);
+    NF_ENC_LAYER256(OFF_L2, OFF_L3, B_L3, 16, 0);
+    // layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246)
+    NF_PE_B(0); nf_chunk<NT, 16, true>(acc, st.wa, bj, st.bias);
+    nf_load_w16<16>(st.wa, Wi, OFF_L3 / 4 + 4 * 16 * 64, lane);
+    nf_read_b<NT>(st.b0, act4, lane, 0);
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L3 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+    }
+    nf_seg_lds<NT, 16, false, true>(acc, st, Wi, OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L4 / 4, Ci, B_L4, act4, lane);
+    NF_ENC_LAYER256(OFF_L4, OFF_L5, B_L5, 16, 1);
+    NF_ENC_LAYER256(OFF_L5, OFF_FEAT, B_FEAT, 16, 1);
+    NF_ENC_LAYER256(OFF_FEAT, OFF_D0E, B_D0, 9, 1);             // fc_feat: no activation (M:250), layers_dir.0 reads it as stored
+#undef NF_ENC_LAYER256
+#undef NF_PE_B
+    // layers_dir.0 : [feat | 24 direction columns] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2)
     float sigma_raw[NT];
+    {
+        f32x4 wd[16];
+        nf_load_w16<9>(wd, Wi, OFF_D0E / 4 + 16 * 9 * 64, lane);
+        nf_seg_lds<NT, 9, true, false>(acc, st, Wi, OFF_D0E / 4, 16, act4, lane);
+        nf_pending_b<NT, false>(bj, st);
+        nf_chunk<NT, 9, false>(acc, st.wb, bj, st.bias);
+        nf_load_w16<9>(st.wb, Wi, OFF_D0E / 4 + 17 * 9 * 64, lane);
 #pragma unroll
-    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
-    nf_store_act<NT, 8, true>(acc, act4, lane);
-    nf_init_acc<NT, 8>(acc, cond + B_D1, lane);
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_D1 / 4, 8, act4, lane);
-    nf_store_act<NT, 8, true>(acc, act4, lane);
-    nf_init_acc<NT, 8>(acc, cond + B_D2, lane);
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_D2 / 4, 8, act4, lane);
-    nf_store_act<NT, 8, true>(acc, act4, lane);
-    nf_init_acc<NT, 1>(acc, cond + B_RGB, lane);
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_RGB / 4, 8, act4, lane);
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_chunk<NT, 9, false>(acc, wd, bj, st.bias);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][1];
+        nf_tail<NT, 9, 8, 8, 1>(acc, st.wb, bj, st, Wi, OFF_D1 / 4, Ci, B_D1, act4, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
+    }
+    nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D1 / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 8, 8, 8, 1>(acc, st.wb, bj, st, Wi, OFF_D2 / 4, Ci, B_D2, act4, lane);
+    nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D2 / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {

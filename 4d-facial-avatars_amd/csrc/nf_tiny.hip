@@ -5,6 +5,7 @@
 #include <vector>
 #include <mutex>
 #include "nf_mlp_dev.h"
+#include "nf_mlp_stream.h"
 #include "nf_pack.h"
 
 namespace nft {
@@ -63,7 +64,6 @@ k_tiny_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ ro, c
     const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) return;
     f32x4* act4 = lds + wave * (16 * NT * 64);
-    const f32x4* W = reinterpret_cast<const f32x4*>(packed);
     f32x4 pe[NT][4];
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
@@ -80,19 +80,46 @@ k_tiny_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ ro, c
             for (int j = 0; j < 4; ++j) *reinterpret_cast<f32x4*>(saved + (int64_t)T_PE * n_points + p * 64 + 16 * j + 4 * g) = pe[t][j];
         }
     }
+    // Layer-streamed like the paper model's kernels (nf_mlp_stream.h): the bias is the C operand of a layer's first MFMAs, the raw
+    // accumulators go to the slab under the last K chunk, the ReLU is applied where the slab is read; SAVE: the post-ReLU copy of the slab
+    // to `saved` rides in the loop that consumes it (NfCopyH: 128-wide rows, two per instruction).  The biases live in the weight image.
     f32x4 acc[NT][16];
-    nf_init_acc<NT, 8>(acc, packed + OFF_B, lane);
-    nf_mma_from_regs<NT, 8, 4>(acc, W + OFF_1 / 4, pe, lane);
-    nf_relu_inplace<NT, 8>(acc);
-    if (SAVE) nf_store_global<NT, 8>(acc, saved + (int64_t)T_H1 * n_points, 128, p0, n_points, lane);
-    nf_store_act<NT, 8, false>(acc, act4, lane);
-    nf_init_acc<NT, 8>(acc, packed + OFF_B + 128, lane);
-    nf_mma_from_lds<NT, 8>(acc, W + OFF_2 / 4, 8, act4, lane);
-    nf_relu_inplace<NT, 8>(acc);
-    if (SAVE) nf_store_global<NT, 8>(acc, saved + (int64_t)T_H2 * n_points, 128, p0, n_points, lane);
-    nf_store_act<NT, 8, false>(acc, act4, lane);
-    nf_init_acc<NT, 1>(acc, packed + OFF_B + 256, lane);
-    nf_mma_from_lds<NT, 1>(acc, W + OFF_3 / 4, 8, act4, lane);
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    uint64_t m64[NT];                                            // not collected here (the backward reads [h > 0] off the saved rows)
+    const NfW Wi = nf_w_image(packed, PACKED);
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    nf_load_bias<8>(st.bias, Wi, OFF_B, lane);
+    {
+        f32x4 w[16];
+        nf_load_w16<8>(w, Wi, OFF_1 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 8, true>(acc, w, bj, st.bias);
+        nf_load_w16<8>(w, Wi, OFF_1 / 4 + 1 * 8 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 8, false>(acc, w, bj, st.bias);
+        nf_load_w16<8>(w, Wi, OFF_1 / 4 + 2 * 8 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 8, false>(acc, w, bj, st.bias);
+        nf_load_w16<8>(w, Wi, OFF_1 / 4 + 3 * 8 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 8, 8, 8, 1>(acc, w, bj, st, Wi, OFF_2 / 4, Wi, OFF_B + 128, act4, lane);
+    }
+#undef NF_PE_B
+    if constexpr (SAVE) {
+        NfCopyH<32, 4, true> cs{act4, nf_slab_copy(saved, T_H1, 128, p0, n_points), lane, 4, {}};
+        cs.prime();
+        nf_seg_lds<NT, 8, true, true, false>(acc, st, Wi, OFF_2 / 4, 8, act4, lane, cs, m64);
+    } else {
+        nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_2 / 4, 8, act4, lane);
+    }
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_3 / 4, Wi, OFF_B + 256, act4, lane);
+    if constexpr (SAVE) {
+        NfCopyH<32, 4, true> cs{act4, nf_slab_copy(saved, T_H2, 128, p0, n_points), lane, 4, {}};
+        cs.prime();
+        nf_seg_lds<NT, 1, true, true, false>(acc, st, Wi, OFF_3 / 4, 8, act4, lane, cs, m64);
+    } else {
+        nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_3 / 4, 8, act4, lane);
+    }
+    nf_pending_b<NT, true>(bj, st);
+    nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
     if (g == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
