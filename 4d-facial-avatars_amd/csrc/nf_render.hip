@@ -439,31 +439,88 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // K6+K7, the shipped sizes (Nc <= 128, Nf <= 128: 64 + 128 in eval, 64 + 64 in training): the same results as
-// k_resample_merge from a wave that never waits for the block and never runs one lane alone.
+// k_resample_merge from a wave that never waits for the block, never runs one lane alone and keeps its cross-lane traffic on
+// the vector unit (DPP / v_permlane*_swap) instead of the LDS crossbar.  The kernel is VALU-issue-bound (64 rays per SIMD, a
+// few hundred instructions each), so every stage is written for instruction count:
 //   * the torch-exact CDF table (nf_build_cdf's arithmetic) without block barriers -- the tables are wave-private and one
 //     wave's LDS instructions execute in order -- and with the sequential DOUBLE cumsum (62 dependent adds on one lane)
-//     replaced by a wave prefix sum in double WHERE THAT IS EXACT: if every pdf entry is 0 or >= 2^-28 and their sum is
-//     below 2, every partial sum is a multiple of 2^-51 below 2, i.e. representable in double -- no addition rounds, so
-//     the association order cannot matter and the scan equals torch's sequential loop bit for bit.  (pdf = (w + 1e-5) / sum
-//     >= 1.6e-7 for weights in [0, 1]: the guard holds for every ray of the hot path; any other input takes the one-lane loop.)
-//   * the Nf samples are sorted in registers (bitonic network over 2 values per lane, cross-lane exchanges), the coarse depths
-//     are sorted already (stratified samples; checked, else the general kernel's full sort runs), and the two lists are MERGED
-//     by rank: out[i + #{B < A[i]}] = A[i], out[j + #{A <= B[j]}] = B[j] (binary searches, no barriers).  The sorted multiset
-//     is what torch.sort returns (T:126 keeps the values only), whatever the algorithm.
+//     replaced by a DPP wave prefix sum in double WHERE THAT IS EXACT: if every pdf entry is 0 or has 2^-22 <= |p| < 2, every
+//     entry is a multiple of 2^-45 and every sum of up to 126 of them is a multiple of 2^-45 below 2^8, i.e. representable
+//     in double -- no addition rounds, so the association order cannot matter and the scan equals torch's sequential loop
+//     bit for bit.  (pdf = (w + 1e-5) / sum >= 9.9e-6 for weights in [0, 1]: the guard holds for every ray of the hot path;
+//     any other input takes the one-lane loop.)
+//   * searchsorted(right) as a branch-free descent over power-of-two steps (the count of table entries <= u);
+//   * the Nf samples are sorted in registers: a bitonic network over 2 values per lane whose exchanges at lane distance 1, 2,
+//     8 are DPP-fused v_min / v_max, at distance 4 two banked DPP moves, and at distance 16 / 32 / 64 IN-LANE min / max after
+//     v_permlane16_swap / v_permlane32_swap have moved the element-index bit concerned into the register index (the element
+//     an entry holds is tracked through the layout changes; nothing is moved back).  Samples that come out of the inverse CDF
+//     ascending already (deterministic abscissae) skip the network;
+//   * the merge with the coarse depths (ascending: checked, else the general kernel's full sort runs) is by counting: a
+//     sample from bin b lies between the bin's mid-points, i.e. z[b] <= s <= z[b+2], so its rank among the depths is b + 1 or
+//     b + 2 -- three LDS reads decide and verify (any lane that cannot verify sends the wave to the binary search); an LDS
+//     histogram of those ranks, prefix-summed (DPP), gives every depth its output slot i + #{samples < z[i]}; the sorted
+//     samples fill the remaining slots in order, which each OUTPUT slot works out for itself from a ballot of the depth slots
+//     (no scatter, the row leaves coalesced).  The sorted multiset is what torch.sort returns (T:126 keeps the values only).
 // ---------------------------------------------------------------------------------------------
 #define NF_RS_MAXC 128
 #define NF_RS_MAXF 128
-__device__ __forceinline__ double nf_shfl_up_f64(double v, int d) {
-    const unsigned long long b = __double_as_longlong(v);
-    const unsigned lo = __shfl_up((unsigned)b, d, 64), hi = __shfl_up((unsigned)(b >> 32), d, 64);
-    return __longlong_as_double(((unsigned long long)hi << 32) | lo);
-}
-// wave-private version of nf_build_cdf (same arithmetic, see there); n_w <= NF_RS_MAXC - 2; every lane of the wave calls it
-__device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_row, int n_w, float* lds_cdf) {
-    const int lane = nf_lane();
-    float* x = lds_cdf + 1;
-    for (int i = lane; i < n_w; i += 64) x[i] = nf_add(w_row[i], 1e-5f);
+// floats per wave: cdf[128] | lb[128] (both dead after the inversion: the slot flags alias them) | A[128] B[128] | x[128] / hist[132]
+#define NF_RS_FLOATS (128 + 128 + 256 + 132)
+#define NF_DPP_XOR1 0xB1                                    // quad_perm:[1,0,3,2]
+#define NF_DPP_XOR2 0x4E                                    // quad_perm:[2,3,0,1]
+#define NF_DPP_ROW_SHL(n) (0x100 + (n))                     // lane i <- lane i + n of its row of 16
+#define NF_DPP_ROW_SHR(n) (0x110 + (n))                     // lane i <- lane i - n
+#define NF_DPP_BCAST15 0x142                                // lane 15 of a row -> every lane of the next row
+#define NF_DPP_BCAST31 0x143                                // lane 31 -> every lane of rows 2, 3
+__device__ __forceinline__ void nf_wave_sync() {            // order one wave's LDS accesses for the compiler (the hardware runs them in order)
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     __builtin_amdgcn_wave_barrier();
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool ZERO>
+__device__ __forceinline__ float nf_dpp_f(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, ZERO));
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK, bool ZERO>
+__device__ __forceinline__ int nf_dpp_i(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, ZERO); }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double nf_dpp_d0(double v) {     // the permuted value where a source lane exists and the row is enabled, else 0.0
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xF, ROW_MASK == 0xF);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+// inclusive prefix sums over the 64 lanes (Kogge-Stone inside rows of 16, then the row totals broadcast forward)
+__device__ __forceinline__ double nf_scan64_f64(double a) {
+    a += nf_dpp_d0<NF_DPP_ROW_SHR(1), 0xF>(a);
+    a += nf_dpp_d0<NF_DPP_ROW_SHR(2), 0xF>(a);
+    a += nf_dpp_d0<NF_DPP_ROW_SHR(4), 0xF>(a);
+    a += nf_dpp_d0<NF_DPP_ROW_SHR(8), 0xF>(a);
+    a += nf_dpp_d0<NF_DPP_BCAST15, 0xA>(a);
+    a += nf_dpp_d0<NF_DPP_BCAST31, 0xC>(a);
+    return a;
+}
+__device__ __forceinline__ int nf_scan64_i32(int a) {
+    a += nf_dpp_i<NF_DPP_ROW_SHR(1), 0xF, 0xF, true>(0, a);
+    a += nf_dpp_i<NF_DPP_ROW_SHR(2), 0xF, 0xF, true>(0, a);
+    a += nf_dpp_i<NF_DPP_ROW_SHR(4), 0xF, 0xF, true>(0, a);
+    a += nf_dpp_i<NF_DPP_ROW_SHR(8), 0xF, 0xF, true>(0, a);
+    a += nf_dpp_i<NF_DPP_BCAST15, 0xA, 0xF, false>(0, a);
+    a += nf_dpp_i<NF_DPP_BCAST31, 0xC, 0xF, false>(0, a);
+    return a;
+}
+__device__ __forceinline__ float nf_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// wave-private version of nf_build_cdf (same arithmetic, see there); 1 <= n_w <= NF_RS_MAXC - 2; every lane of the wave calls it;
+// x: scratch of n_w floats.  Leaves cdf[0 .. n_w] in lds_cdf.
+__device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_row, int n_w, float* lds_cdf, float* x, int lane) {
+    float xr[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        xr[r] = 0.0f;
+        if (i < n_w) { xr[r] = nf_add(w_row[i], 1e-5f); x[i] = xr[r]; }
+    }
+    nf_wave_sync();
     float sum;
     if (n_w < 8) {
         float p[4] = {0.f, 0.f, 0.f, 0.f};
@@ -473,130 +530,234 @@ __device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_ro
         for (int i = q * 4; i < n_w; ++i) p[0] = nf_add(p[0], x[i]);
         sum = nf_add(nf_add(nf_add(p[0], p[1]), p[2]), p[3]);                 // (every lane computes the same value)
     } else {
-        const int V = n_w >> 3, q = V >> 2, k = (lane >> 3) & 3, l = lane & 7;
-        float P = 0.0f;                                     // lanes 0..31: P[k][l]
-        for (int i = 0; i < q; ++i) P = nf_add(P, x[((4 * i + k) << 3) + l]);
-        if (k == 0) for (int i = q * 4; i < V; ++i) P = nf_add(P, x[(i << 3) + l]);
-        const float p1 = __shfl(P, 8 + l, 64), p2 = __shfl(P, 16 + l, 64), p3 = __shfl(P, 24 + l, 64);
-        P = nf_add(nf_add(nf_add(P, p1), p2), p3);          // meaningful in lanes 0..7
+        const int V = n_w >> 3, q = V >> 2;
+        const float* xl = x + (lane & 31);                  // lanes 0..31: P[k][l] with 8 k + l = lane
+        float P = 0.0f;
+        for (int i = 0; i < q; ++i) P = nf_add(P, xl[32 * i]);
+        const float* x8 = x + (lane & 7);
+        for (int i = q * 4; i < V; ++i) { const float t = nf_add(P, x8[8 * i]); P = lane < 8 ? t : P; }      // leftover whole vectors -> P[0]
+        // P[0] += P[1], += P[2], += P[3] (lanes 0..7): lane + 8 by a row shift; row 1 (lanes 16..31) brought to row 0 by one swap
+        const float p1 = nf_dpp_f<NF_DPP_ROW_SHL(8), 0xF, 0xF, true>(0.0f, P);
+        const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(P), __float_as_uint(P), false, false);
+        const float R1 = __uint_as_float(sw[1]);            // rows {1, 1, 3, 3} of P
+        const float p3 = nf_dpp_f<NF_DPP_ROW_SHL(8), 0xF, 0xF, true>(0.0f, R1);
+        P = nf_add(nf_add(nf_add(P, p1), R1), p3);          // meaningful in lanes 0..7
         float fin = 0.0f;
         for (int i = V << 3; i < n_w; ++i) fin = nf_add(fin, x[i]);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) fin = nf_add(fin, __shfl(P, j, 64));
-        sum = __shfl(fin, 0, 64);
+        for (int j = 0; j < 8; ++j) fin = nf_add(fin, nf_readlane_f(P, j));
+        sum = fin;
     }
-    // pdf, and the exactness guard of the parallel cumsum
+    // pdf, and the exactness guard of the parallel cumsum (0, or 2^-22 <= |p| < 2; NaN fails)
     float v[2];
     bool ok = true;
-    float mag = 0.0f;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = lane + 64 * r;
-        v[r] = i < n_w ? nf_div(x[i], sum) : 0.0f;
-        ok = ok && (v[r] == 0.0f || (fabsf(v[r]) >= 0x1p-28f && fabsf(v[r]) < 2.0f));     // (NaN fails)
-        mag += fabsf(v[r]);
+        v[r] = i < n_w ? nf_div(xr[r], sum) : 0.0f;
+        const unsigned m = __float_as_uint(v[r]) & 0x7fffffffu;
+        ok = ok && (m == 0u || (m - 0x34800000u) < (0x40000000u - 0x34800000u));
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) mag += __shfl_xor(mag, o, 64);
-    ok = ok && mag < 1.9f;
     if (__all(ok)) {
-        double carry = 0.0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-            double a = (double)v[r];
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const double up = nf_shfl_up_f64(a, d);
-                if (lane >= d) a += up;                     // exact (see above): any order gives torch's sequential result
-            }
-            a += carry;
-            const int i = lane + 64 * r;
-            if (i < n_w) x[i] = (float)a;
-            const unsigned long long b = __double_as_longlong(a);
-            carry = __longlong_as_double(((unsigned long long)__shfl((unsigned)(b >> 32), 63, 64) << 32) | __shfl((unsigned)b, 63, 64));
+        double a0 = nf_scan64_f64((double)v[0]);
+        if (lane < n_w) x[lane] = (float)a0;
+        if (n_w > 64) {
+            const unsigned long long b = __double_as_longlong(a0);
+            const double carry = __longlong_as_double(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) |
+                                                      (unsigned)__builtin_amdgcn_readlane((int)b, 63));
+            const double a1 = nf_scan64_f64((double)v[1]) + carry;
+            if (lane + 64 < n_w) x[lane + 64] = (float)a1;
         }
+        nf_wave_sync();
+#pragma unroll
+        for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < n_w) lds_cdf[1 + i] = x[i]; }
         if (lane == 0) lds_cdf[0] = 0.0f;
     } else {
 #pragma unroll
         for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < n_w) x[i] = v[r]; }
-        __builtin_amdgcn_wave_barrier();
+        nf_wave_sync();
         if (lane == 0) {
             lds_cdf[0] = 0.0f;
             double acc = 0.0;
-            for (int i = 0; i < n_w; ++i) { acc += (double)x[i]; x[i] = (float)acc; }
+            for (int i = 0; i < n_w; ++i) { acc += (double)x[i]; lds_cdf[1 + i] = (float)acc; }
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    nf_wave_sync();
 }
 
-// ascending bitonic sort of 128 values held as v[r] = element 64 r + lane
-__device__ __forceinline__ void nf_sort128_regs(float (&v)[2], int lane) {
+// ---- register bitonic sort of 128 values, v[r] = element 64 r + lane on entry ------------------------------------------------------
+// lanes that take the minimum in a compare-exchange at lane-bit JB inside blocks whose direction is lane-bit UB (-1: ascending)
+constexpr unsigned long long nf_takemin_mask(int jb, int ub) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) {
+        const int lower = ((l >> jb) & 1) == 0, up = ub < 0 ? 1 : (((l >> ub) & 1) == 0);
+        if (lower == up) m |= 1ull << l;
+    }
+    return m;
+}
+constexpr unsigned long long nf_bitclear_mask(int b) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; ++l) if (((l >> b) & 1) == 0) m |= 1ull << l;
+    return m;
+}
+// v <- lane-mask ? min(v, partner) : max(v, partner); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not see
+#define NF_CE_DPP(V_, CTRL_, MASK_)                                                                                       \
+    do {                                                                                                                  \
+        float mn_, mx_;                                                                                                   \
+        asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 " CTRL_ " row_mask:0xf bank_mask:0xf\n\t"                                \
+            "v_max_f32_dpp %1, %2, %2 " CTRL_ " row_mask:0xf bank_mask:0xf" : "=&v"(mn_), "=&v"(mx_) : "v"(V_));          \
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(V_) : "v"(mx_), "v"(mn_), "s"(MASK_));                              \
+    } while (0)
+#define NF_CE_DPP4(V_, MASK_)                                                                                             \
+    do {                                                                                                                  \
+        float o_, mn_, mx_;                                                                                               \
+        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                                     \
+            "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(o_) : "v"(V_));                           \
+        asm("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(mn_), "=&v"(mx_) : "v"(V_), "v"(o_));                  \
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(V_) : "v"(mx_), "v"(mn_), "s"(MASK_));                              \
+    } while (0)
+// one DPP level (lane distances 8, 4, 2, 1 as asked) on both registers
+template <int JB, int UB>
+__device__ __forceinline__ void nf_ce_lane(float (&v)[2]) {
+    constexpr unsigned long long M = nf_takemin_mask(JB, UB);
 #pragma unroll
-    for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) {                                  // elements lane and 64 + lane: both directions "up" (k = 128)
-                const float lo = fminf(v[0], v[1]), hi = fmaxf(v[0], v[1]);
-                v[0] = lo; v[1] = hi;
-            } else {
-#pragma unroll
-                for (int r = 0; r < 2; ++r) {
-                    const float o = __shfl_xor(v[r], j, 64);
-                    const bool lower = (lane & j) == 0, up = ((64 * r + lane) & k) == 0;      // (element index = 64 r + lane)
-                    v[r] = (lower == up) ? fminf(v[r], o) : fmaxf(v[r], o);
-                }
-            }
-        }
+    for (int r = 0; r < 2; ++r) {
+        if constexpr (JB == 0) NF_CE_DPP(v[r], "quad_perm:[1,0,3,2]", M);
+        else if constexpr (JB == 1) NF_CE_DPP(v[r], "quad_perm:[2,3,0,1]", M);
+        else if constexpr (JB == 2) NF_CE_DPP4(v[r], M);
+        else NF_CE_DPP(v[r], "row_ror:8", M);
     }
 }
+template <int JB_TOP, int UB>
+__device__ __forceinline__ void nf_ce_lane_down(float (&v)[2]) {
+    if constexpr (JB_TOP >= 3) nf_ce_lane<3, UB>(v);
+    if constexpr (JB_TOP >= 2) nf_ce_lane<2, UB>(v);
+    if constexpr (JB_TOP >= 1) nf_ce_lane<1, UB>(v);
+    nf_ce_lane<0, UB>(v);
+}
+// the element-index bit held by the register index trades places with lane bit 4 (SWAP16) or 5
+template <bool SWAP16>
+__device__ __forceinline__ void nf_sort_swap(float (&v)[2]) {
+    if constexpr (SWAP16) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
+    else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
+}
+// compare-exchange between the two registers of a lane; UB: lane bit that holds the direction (-1: ascending everywhere)
+template <int UB>
+__device__ __forceinline__ void nf_ce_regs(float (&v)[2]) {
+    float lo, hi;
+    asm("s_nop 1\n\tv_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(v[0]), "v"(v[1]));
+    if constexpr (UB < 0) { v[0] = lo; v[1] = hi; }
+    else {
+        constexpr unsigned long long UP = nf_bitclear_mask(UB);
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v[0]) : "v"(hi), "v"(lo), "s"(UP));
+        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v[1]) : "v"(lo), "v"(hi), "s"(UP));
+    }
+}
+// Ascending sort.  On exit register r of lane l holds sorted element ((l >> 5) << 6) | (((l >> 4) & 1) << 5) | (r << 4) | (l & 15).
+__device__ __forceinline__ void nf_sort128_regs(float (&v)[2]) {
+    // element bits: b0..b3 = lane bits 0..3 throughout; (register, lane bit 4, lane bit 5) = (b6, b4, b5) on entry
+    nf_ce_lane_down<0, 1>(v);                               // k = 2
+    nf_ce_lane_down<1, 2>(v);                               // k = 4
+    nf_ce_lane_down<2, 3>(v);                               // k = 8
+    nf_ce_lane_down<3, 4>(v);                               // k = 16 (direction: b4 = lane bit 4)
+    nf_sort_swap<true>(v);                                  // k = 32: (b4, b6, b5)
+    nf_ce_regs<5>(v);
+    nf_ce_lane_down<3, 5>(v);
+    nf_sort_swap<false>(v);                                 // k = 64 (direction b6 = lane bit 4): (b5, b6, b4)
+    nf_ce_regs<4>(v);
+    nf_sort_swap<false>(v);                                 //          (b4, b6, b5)
+    nf_ce_regs<4>(v);
+    nf_ce_lane_down<3, 4>(v);
+    nf_sort_swap<true>(v);                                  // k = 128 (ascending): (b6, b4, b5)
+    nf_ce_regs<-1>(v);
+    nf_sort_swap<false>(v);                                 //          (b5, b4, b6)
+    nf_ce_regs<-1>(v);
+    nf_sort_swap<true>(v);                                  //          (b4, b5, b6)
+    nf_ce_regs<-1>(v);
+    nf_ce_lane_down<3, -1>(v);
+}
+__device__ __forceinline__ int nf_sort128_index(int r, int lane) { return ((lane >> 5) << 6) | (((lane >> 4) & 1) << 5) | (r << 4) | (lane & 15); }
 
 __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __restrict__ zc, const float* __restrict__ wc,
                                                               const float* __restrict__ u, int64_t u_stride, int64_t n_rays,
                                                               int nc, int nf, float* __restrict__ z_samples,
                                                               float* __restrict__ z_fine) {
-    __shared__ float lds[NF_RAYS_PER_BLOCK][3 * NF_RS_MAXC + NF_RS_MAXF + NF_RS_MAXC + NF_RS_MAXF];
-    const int lane = nf_lane(), wv = threadIdx.x >> 6;
+    __shared__ float lds[NF_RAYS_PER_BLOCK][NF_RS_FLOATS];
+    const int lane = nf_lane();
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
     if (ray >= n_rays) return;                              // wave-uniform; no block barrier below
     float* cdf = lds[wv];
-    float* lb = cdf + NF_RS_MAXC;
-    float* A = lb + NF_RS_MAXC;                             // coarse depths (nc)
-    float* B = A + NF_RS_MAXC;                              // sorted samples (nf)
-    float* out = B + NF_RS_MAXF;                            // merged (nc + nf)
+    float* lb = cdf + 128;
+    int* flags = reinterpret_cast<int*>(cdf);               // (cdf, lb are dead by then)
+    float* A = lb + 128;                                    // coarse depths (nc)
+    float* B = A + 128;                                     // sorted samples (nf)
+    float* xs = B + 128;
+    int* hist = reinterpret_cast<int*>(xs);                 // (the pdf scratch is dead by then)
     const int n_bins = nc - 1, nt = nc + nf;
-    nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf);
+    const float* zrow = zc + ray * nc;
+    const float* urow = u + ray * u_stride;
+    nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf, xs, lane);
+    float zr[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int i = lane + 64 * r;
+        zr[r] = 0.0f;
+        if (i < nc) { zr[r] = zrow[i]; A[i] = zr[r]; }
+    }
+    for (int i = lane; i <= nc; i += 64) hist[i] = 0;
+    nf_wave_sync();
     bool sorted = true;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = lane + 64 * r;
-        if (i < nc) {
-            const float zi = zc[ray * nc + i];
-            A[i] = zi;
-            if (i < n_bins) {
-                const float zn = zc[ray * nc + i + 1];
-                lb[i] = nf_mul(0.5f, nf_add(zn, zi));
-                sorted = sorted && zi <= zn;
-            }
+        if (i < n_bins) {
+            const float zn = A[i + 1];
+            lb[i] = nf_mul(0.5f, nf_add(zn, zr[r]));
+            sorted = sorted && zr[r] <= zn;
         }
     }
-    __builtin_amdgcn_wave_barrier();
+    nf_wave_sync();
+    // ---- inverse CDF (H:368-387): count = #{cdf <= u} by descent, then the interpolation of nf_invert_cdf ---------------------------
     float v[2];
+    int below[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int j = lane + 64 * r;
         v[r] = INFINITY;
+        below[r] = 0;
         if (j < nf) {
-            v[r] = nf_invert_cdf(cdf, lb, n_bins, u[ray * u_stride + j]);
+            const float uu = urow[j];
+            int pos = 0;
+            if (n_bins >= 64) pos = cdf[63] <= uu ? 64 : 0;
+#pragma unroll
+            for (int st = 32; st > 0; st >>= 1) {
+                const int t = pos + st;
+                const float c = cdf[t - 1];                 // (inside the table's 128 floats for every t <= 127)
+                pos = (t <= n_bins && c <= uu) ? t : pos;
+            }
+            const int lo = pos;                             // torch.searchsorted(cdf, u, right=True)
+            const int bl = lo - 1 > 0 ? lo - 1 : 0;
+            const int ab = lo < n_bins - 1 ? lo : n_bins - 1;
+            const float cb = cdf[bl], ca = cdf[ab];
+            const float bb = lb[bl], ba = lb[ab];
+            float den = nf_sub(ca, cb);
+            if (den < 1e-5f) den = 1.0f;
+            const float t = nf_div(nf_sub(uu, cb), den);
+            v[r] = nf_add(bb, nf_mul(t, nf_sub(ba, bb)));
+            below[r] = bl;
             if (z_samples) z_samples[ray * nf + j] = v[r];
         }
     }
     if (!__all(sorted)) {                                   // coarse depths not ascending (no caller on the hot path produces such a row):
-        const int np2 = nf_next_pow2(nt);                   // sort the concatenation like k_resample_merge does, wave-private
+        float* out = A;                                     // sort the concatenation like k_resample_merge does, wave-private (A | B = 256 floats;
+                                                            // the depths are in place, the samples follow them directly)
+        const int np2 = nf_next_pow2(nt);
+        nf_wave_sync();
 #pragma unroll
         for (int r = 0; r < 2; ++r) { const int j = lane + 64 * r; if (j < nf) out[nc + j] = v[r]; }
-        for (int i = lane; i < nc; i += 64) out[i] = A[i];
         for (int i = nt + lane; i < np2; i += 64) out[i] = INFINITY;
-        __builtin_amdgcn_wave_barrier();
+        nf_wave_sync();
         for (int k = 2; k <= np2; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int t = lane; t < (np2 >> 1); t += 64) {
@@ -605,34 +766,76 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
                     const float a = out[i], b = out[q];
                     if ((a > b) == up) { out[i] = b; out[q] = a; }
                 }
-                __builtin_amdgcn_wave_barrier();
+                nf_wave_sync();
             }
         for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = out[i];
         return;
     }
-    nf_sort128_regs(v, lane);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) { const int j = lane + 64 * r; if (j < nf) B[j] = v[r]; }
-    __builtin_amdgcn_wave_barrier();
-    // merge by rank
+    // ---- rank of every sample among the depths, #{A <= s}: bin b = below -> b + 1 or b + 2, verified -------------------------------
+    int rank[2];
+    bool ok = true;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int i = lane + 64 * r;
-        if (i < nc) {
-            const float a = A[i];
-            int lo = 0, hi = nf;                            // #{B < a}
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (B[mid] < a) lo = mid + 1; else hi = mid; }
-            out[i + lo] = a;
-        }
-        if (i < nf) {
-            const float b = v[r];                           // B[i]
-            int lo = 0, hi = nc;                            // #{A <= b}
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] <= b) lo = mid + 1; else hi = mid; }
-            out[i + lo] = b;
+        const int j = lane + 64 * r;
+        rank[r] = 0;
+        if (j < nf) {
+            const int g = below[r] + 1;                     // 1 <= g <= nc - 1
+            const int g2 = g + 1 < nc ? g + 1 : nc - 1;
+            const float a0 = A[g - 1], a1 = A[g], a2 = A[g2];
+            rank[r] = g + (a1 <= v[r] ? 1 : 0);
+            ok = ok && a0 <= v[r] && (g + 1 >= nc || !(a2 <= v[r]));
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    for (int i = lane; i < nt; i += 64) z_fine[ray * nt + i] = out[i];
+    if (!__all(ok)) {                                       // (degenerate spacing, NaN: the binary search of the round-4 kernel)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const float b = v[r];
+            int lo = 0, hi = nc;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (A[mid] <= b) lo = mid + 1; else hi = mid; }
+            rank[r] = lo;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+        if (lane + 64 * r < nf) __hip_atomic_fetch_add(&hist[rank[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    // ---- the samples in ascending order -> B -------------------------------------------------------------------------------------
+    {
+        const float nx0 = __shfl_down(v[0], 1, 64), nx1 = __shfl_down(v[1], 1, 64), first1 = nf_readlane_f(v[1], 0);
+        const bool asc = v[0] <= (lane < 63 ? nx0 : first1) && (lane == 63 || v[1] <= nx1);
+        if (__all(asc)) {
+#pragma unroll
+            for (int r = 0; r < 2; ++r) B[lane + 64 * r] = v[r];
+        } else {
+            nf_sort128_regs(v);
+#pragma unroll
+            for (int r = 0; r < 2; ++r) B[nf_sort128_index(r, lane)] = v[r];
+        }
+    }
+    // ---- slots of the depths: i + #{samples < z[i]} = i + #{samples of rank <= i} ---------------------------------------------------
+    for (int i = lane; i < nt; i += 64) flags[i] = 0;
+    nf_wave_sync();
+    {
+        const int h0 = lane < nc ? hist[lane] : 0;
+        const int p0 = nf_scan64_i32(h0);
+        if (lane < nc) flags[lane + p0] = 1;
+        if (nc > 64) {
+            const int carry = __builtin_amdgcn_readlane(p0, 63);
+            const int h1 = lane + 64 < nc ? hist[lane + 64] : 0;
+            const int p1 = nf_scan64_i32(h1) + carry;
+            if (lane + 64 < nc) flags[lane + 64 + p1] = 1;
+        }
+    }
+    nf_wave_sync();
+    // ---- every output slot fetches its value: the c-th depth, or the (slot - c)-th sample, c = depth slots before it ------------------
+    int before = 0;
+    for (int s0 = 0; s0 < nt; s0 += 64) {
+        const int s = s0 + lane;
+        const bool dep = s < nt && flags[s] != 0;
+        const unsigned long long m = __ballot(dep);
+        const int c = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+        if (s < nt) z_fine[ray * nt + s] = A[dep ? c : 128 + s - c];
+        before += __popcll(m);
+    }
 }
 
 extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
