@@ -462,6 +462,9 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 //     samples fill the remaining slots in order, which each OUTPUT slot works out for itself from a ballot of the depth slots
 //     (no scatter, the row leaves coalesced).  The sorted multiset is what torch.sort returns (T:126 keeps the values only).
 // ---------------------------------------------------------------------------------------------
+#ifndef NF_RS_STOP
+#define NF_RS_STOP 0
+#endif
 #define NF_RS_MAXC 128
 #define NF_RS_MAXF 128
 // floats per wave: cdf[128] | lb[128] (both dead after the inversion: the slot flags alias them) | A[128] B[128] | x[128] / hist[132]
@@ -511,7 +514,7 @@ __device__ __forceinline__ int nf_scan64_i32(int a) {
 __device__ __forceinline__ float nf_readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 
 // wave-private version of nf_build_cdf (same arithmetic, see there); 1 <= n_w <= NF_RS_MAXC - 2; every lane of the wave calls it;
-// x: scratch of n_w floats.  Leaves cdf[0 .. n_w] in lds_cdf.
+// x: scratch of n_w floats.  Leaves cdf[0 .. n_w] in lds_cdf, padded with +inf to 128 entries.
 __device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_row, int n_w, float* lds_cdf, float* x, int lane) {
     float xr[2];
 #pragma unroll
@@ -559,18 +562,17 @@ __device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_ro
         ok = ok && (m == 0u || (m - 0x34800000u) < (0x40000000u - 0x34800000u));
     }
     if (__all(ok)) {
-        double a0 = nf_scan64_f64((double)v[0]);
-        if (lane < n_w) x[lane] = (float)a0;
+        const double a0 = nf_scan64_f64((double)v[0]);
+        float c1 = INFINITY;                                // entries past the table: +inf (the inversion's descent never looks at a count)
         if (n_w > 64) {
             const unsigned long long b = __double_as_longlong(a0);
             const double carry = __longlong_as_double(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(b >> 32), 63) << 32) |
                                                       (unsigned)__builtin_amdgcn_readlane((int)b, 63));
             const double a1 = nf_scan64_f64((double)v[1]) + carry;
-            if (lane + 64 < n_w) x[lane + 64] = (float)a1;
+            if (lane + 64 < n_w) c1 = (float)a1;
         }
-        nf_wave_sync();
-#pragma unroll
-        for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < n_w) lds_cdf[1 + i] = x[i]; }
+        lds_cdf[1 + lane] = lane < n_w ? (float)a0 : INFINITY;
+        if (lane < 63) lds_cdf[65 + lane] = c1;
         if (lane == 0) lds_cdf[0] = 0.0f;
     } else {
 #pragma unroll
@@ -581,6 +583,7 @@ __device__ __forceinline__ void nf_build_cdf_wave(const float* __restrict__ w_ro
             double acc = 0.0;
             for (int i = 0; i < n_w; ++i) { acc += (double)x[i]; lds_cdf[1 + i] = (float)acc; }
         }
+        for (int i = n_w + 1 + lane; i < 128; i += 64) lds_cdf[i] = INFINITY;
     }
     nf_wave_sync();
 }
@@ -608,14 +611,9 @@ constexpr unsigned long long nf_bitclear_mask(int b) {
             "v_max_f32_dpp %1, %2, %2 " CTRL_ " row_mask:0xf bank_mask:0xf" : "=&v"(mn_), "=&v"(mx_) : "v"(V_));          \
         asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(V_) : "v"(mx_), "v"(mn_), "s"(MASK_));                              \
     } while (0)
-#define NF_CE_DPP4(V_, MASK_)                                                                                             \
-    do {                                                                                                                  \
-        float o_, mn_, mx_;                                                                                               \
-        asm("s_nop 1\n\tv_mov_b32_dpp %0, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"                                     \
-            "v_mov_b32_dpp %0, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(o_) : "v"(V_));                           \
-        asm("v_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(mn_), "=&v"(mx_) : "v"(V_), "v"(o_));                  \
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(V_) : "v"(mx_), "v"(mn_), "s"(MASK_));                              \
-    } while (0)
+// the same with row / bank write masks where the lanes that take the minimum are whole banks of whole rows: every instruction writes its
+// part of T_ (the four parts cover the wave), no select.  P_: partner at lane + 4 ("row_shl:4") or lane - 4 ("row_shr:4") or across 8
+#define NF_CE_PART(OP_, T_, V_, P_, ROWS_, BANKS_) "v_" OP_ "_f32_dpp %0, %1, %1 " P_ " row_mask:" ROWS_ " bank_mask:" BANKS_ "\n\t"
 // one DPP level (lane distances 8, 4, 2, 1 as asked) on both registers
 template <int JB, int UB>
 __device__ __forceinline__ void nf_ce_lane(float (&v)[2]) {
@@ -624,8 +622,27 @@ __device__ __forceinline__ void nf_ce_lane(float (&v)[2]) {
     for (int r = 0; r < 2; ++r) {
         if constexpr (JB == 0) NF_CE_DPP(v[r], "quad_perm:[1,0,3,2]", M);
         else if constexpr (JB == 1) NF_CE_DPP(v[r], "quad_perm:[2,3,0,1]", M);
-        else if constexpr (JB == 2) NF_CE_DPP4(v[r], M);
-        else NF_CE_DPP(v[r], "row_ror:8", M);
+        else if constexpr (JB == 2) {
+            // lane distance 4: banks 0, 2 of a row are the lower lanes (partner at + 4), banks 1, 3 the upper ones (partner at - 4)
+            float t;
+            if constexpr (UB < 0)                           // ascending everywhere
+                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0xf", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0xf", "0xa")
+                    : "=&v"(t) : "v"(v[r]));
+            else if constexpr (UB == 3)                     // direction = lane bit 3: banks 0, 1 ascending, banks 2, 3 descending
+                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0xf", "0x1") NF_CE_PART("max", t, v, "row_shr:4", "0xf", "0x2")
+                    NF_CE_PART("max", t, v, "row_shl:4", "0xf", "0x4") NF_CE_PART("min", t, v, "row_shr:4", "0xf", "0x8") : "=&v"(t) : "v"(v[r]));
+            else if constexpr (UB == 4)                     // direction = lane bit 4: rows 0, 2 ascending, rows 1, 3 descending
+                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0x5", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0x5", "0xa")
+                    NF_CE_PART("max", t, v, "row_shl:4", "0xa", "0x5") NF_CE_PART("min", t, v, "row_shr:4", "0xa", "0xa") : "=&v"(t) : "v"(v[r]));
+            else                                            // direction = lane bit 5: rows 0, 1 ascending, rows 2, 3 descending
+                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0x3", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0x3", "0xa")
+                    NF_CE_PART("max", t, v, "row_shl:4", "0xc", "0x5") NF_CE_PART("min", t, v, "row_shr:4", "0xc", "0xa") : "=&v"(t) : "v"(v[r]));
+            v[r] = t;
+        } else if constexpr (UB < 0) {                      // lane distance 8, ascending everywhere: banks 0, 1 keep the minimum
+            float t;
+            asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_ror:8", "0xf", "0x3") NF_CE_PART("max", t, v, "row_ror:8", "0xf", "0xc") : "=&v"(t) : "v"(v[r]));
+            v[r] = t;
+        } else NF_CE_DPP(v[r], "row_ror:8", M);
     }
 }
 template <int JB_TOP, int UB>
@@ -697,14 +714,20 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     const int n_bins = nc - 1, nt = nc + nf;
     const float* zrow = zc + ray * nc;
     const float* urow = u + ray * u_stride;
-    nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf, xs, lane);
-    float zr[2];
+    // every global read of the row is requested before the table is built (their latency runs under it)
+    float zr[2], ur[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = lane + 64 * r;
-        zr[r] = 0.0f;
-        if (i < nc) { zr[r] = zrow[i]; A[i] = zr[r]; }
+        zr[r] = i < nc ? zrow[i] : 0.0f;
+        ur[r] = i < nf ? urow[i] : 0.0f;
     }
+    nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf, xs, lane);
+#if NF_RS_STOP == 1
+    if (cdf[lane] != 12345.f) return;
+#endif
+#pragma unroll
+    for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < nc) A[i] = zr[r]; }
     for (int i = lane; i <= nc; i += 64) hist[i] = 0;
     nf_wave_sync();
     bool sorted = true;
@@ -722,33 +745,31 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     float v[2];
     int below[2];
 #pragma unroll
-    for (int r = 0; r < 2; ++r) {
+    for (int r = 0; r < 2; ++r) {                           // (lanes past nf run along on u = 0: no branches, the two descents interleave)
         const int j = lane + 64 * r;
-        v[r] = INFINITY;
-        below[r] = 0;
-        if (j < nf) {
-            const float uu = urow[j];
-            int pos = 0;
-            if (n_bins >= 64) pos = cdf[63] <= uu ? 64 : 0;
+        const float uu = ur[r];
+        // the table is padded with +inf to 128 entries: no bound checks inside; u = +inf (counts the padding) is clamped after
+        int pos = 0;
+        if (n_bins >= 64) pos = cdf[63] <= uu ? 64 : 0;
 #pragma unroll
-            for (int st = 32; st > 0; st >>= 1) {
-                const int t = pos + st;
-                const float c = cdf[t - 1];                 // (inside the table's 128 floats for every t <= 127)
-                pos = (t <= n_bins && c <= uu) ? t : pos;
-            }
-            const int lo = pos;                             // torch.searchsorted(cdf, u, right=True)
-            const int bl = lo - 1 > 0 ? lo - 1 : 0;
-            const int ab = lo < n_bins - 1 ? lo : n_bins - 1;
-            const float cb = cdf[bl], ca = cdf[ab];
-            const float bb = lb[bl], ba = lb[ab];
-            float den = nf_sub(ca, cb);
-            if (den < 1e-5f) den = 1.0f;
-            const float t = nf_div(nf_sub(uu, cb), den);
-            v[r] = nf_add(bb, nf_mul(t, nf_sub(ba, bb)));
-            below[r] = bl;
-            if (z_samples) z_samples[ray * nf + j] = v[r];
-        }
+        for (int st = 32; st > 0; st >>= 1) pos += cdf[pos + st - 1] <= uu ? st : 0;
+        pos = pos < n_bins ? pos : n_bins;
+        const int lo = pos;                                 // torch.searchsorted(cdf, u, right=True)
+        const int bl = lo - 1 > 0 ? lo - 1 : 0;
+        const int ab = lo < n_bins - 1 ? lo : n_bins - 1;
+        const float cb = cdf[bl], ca = cdf[ab];
+        const float bb = lb[bl], ba = lb[ab];
+        float den = nf_sub(ca, cb);
+        if (den < 1e-5f) den = 1.0f;
+        const float t = nf_div(nf_sub(uu, cb), den);
+        const float val = nf_add(bb, nf_mul(t, nf_sub(ba, bb)));
+        v[r] = j < nf ? val : INFINITY;
+        below[r] = bl;
+        if (z_samples && j < nf) z_samples[ray * nf + j] = val;
     }
+#if NF_RS_STOP == 2
+    if (v[0] + v[1] != 12345.f) return;
+#endif
     if (!__all(sorted)) {                                   // coarse depths not ascending (no caller on the hot path produces such a row):
         float* out = A;                                     // sort the concatenation like k_resample_merge does, wave-private (A | B = 256 floats;
                                                             // the depths are in place, the samples follow them directly)
@@ -776,15 +797,11 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     bool ok = true;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int j = lane + 64 * r;
-        rank[r] = 0;
-        if (j < nf) {
-            const int g = below[r] + 1;                     // 1 <= g <= nc - 1
-            const int g2 = g + 1 < nc ? g + 1 : nc - 1;
-            const float a0 = A[g - 1], a1 = A[g], a2 = A[g2];
-            rank[r] = g + (a1 <= v[r] ? 1 : 0);
-            ok = ok && a0 <= v[r] && (g + 1 >= nc || !(a2 <= v[r]));
-        }
+        const int g = below[r] + 1;                         // 1 <= g <= nc - 1
+        const int g2 = g + 1 < nc ? g + 1 : nc - 1;
+        const float a0 = A[g - 1], a1 = A[g], a2 = A[g2];
+        rank[r] = g + (a1 <= v[r] ? 1 : 0);
+        ok = ok && (lane + 64 * r >= nf || (a0 <= v[r] && (g + 1 >= nc || !(a2 <= v[r]))));
     }
     if (!__all(ok)) {                                       // (degenerate spacing, NaN: the binary search of the round-4 kernel)
 #pragma unroll
@@ -798,6 +815,9 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
 #pragma unroll
     for (int r = 0; r < 2; ++r)
         if (lane + 64 * r < nf) __hip_atomic_fetch_add(&hist[rank[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+#if NF_RS_STOP == 3
+    if (rank[0] + rank[1] != -5) return;
+#endif
     // ---- the samples in ascending order -> B -------------------------------------------------------------------------------------
     {
         const float nx0 = __shfl_down(v[0], 1, 64), nx1 = __shfl_down(v[1], 1, 64), first1 = nf_readlane_f(v[1], 0);
@@ -811,6 +831,9 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
             for (int r = 0; r < 2; ++r) B[nf_sort128_index(r, lane)] = v[r];
         }
     }
+#if NF_RS_STOP == 4
+    if (v[0] + v[1] != 12345.f) return;
+#endif
     // ---- slots of the depths: i + #{samples < z[i]} = i + #{samples of rank <= i} ---------------------------------------------------
     for (int i = lane; i < nt; i += 64) flags[i] = 0;
     nf_wave_sync();
@@ -828,14 +851,17 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     nf_wave_sync();
     // ---- every output slot fetches its value: the c-th depth, or the (slot - c)-th sample, c = depth slots before it ------------------
     int before = 0;
-    for (int s0 = 0; s0 < nt; s0 += 64) {
-        const int s = s0 + lane;
-        const bool dep = s < nt && flags[s] != 0;
+    auto round = [&](int q) {
+        const int s = 64 * q + lane;
+        const bool dep = s < nt && flags[s] != 0;           // (flags: 256 entries, zeroed up to nt)
         const unsigned long long m = __ballot(dep);
         const int c = before + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-        if (s < nt) z_fine[ray * nt + s] = A[dep ? c : 128 + s - c];
+        const float val = A[dep ? c : 128 + ((s - c) & 127)];
+        if (s < nt) z_fine[ray * nt + s] = val;
         before += __popcll(m);
-    }
+    };
+    round(0); round(1);                                     // (independent up to the running count: their LDS reads overlap)
+    if (nt > 128) { round(2); round(3); }
 }
 
 extern "C" int nf_resample_merge(const float* z_coarse, const float* w_coarse, const float* u, int64_t u_row_stride,
