@@ -450,11 +450,11 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 //     bit for bit.  (pdf = (w + 1e-5) / sum >= 9.9e-6 for weights in [0, 1]: the guard holds for every ray of the hot path;
 //     any other input takes the one-lane loop.)
 //   * searchsorted(right) as a branch-free descent over power-of-two steps (the count of table entries <= u);
-//   * the Nf samples are sorted in registers: a bitonic network over 2 values per lane whose exchanges at lane distance 1, 2,
-//     8 are DPP-fused v_min / v_max, at distance 4 two banked DPP moves, and at distance 16 / 32 / 64 IN-LANE min / max after
-//     v_permlane16_swap / v_permlane32_swap have moved the element-index bit concerned into the register index (the element
-//     an entry holds is tracked through the layout changes; nothing is moved back).  Samples that come out of the inverse CDF
-//     ascending already (deterministic abscissae) skip the network;
+//   * the Nf samples are sorted in registers: a bitonic network over 2 values per lane, ONE v_min per compare-exchange (sign-domain
+//     trick, see nf_sort128_regs): exchanges at lane distance 1, 2, 8 are a DPP-fused v_min, at distance 4 two banked ones, and at
+//     distance 16 / 32 / 64 IN-LANE after v_permlane16_swap / v_permlane32_swap have moved the element-index bit concerned into the
+//     register index (the element an entry holds is tracked through the layout changes; nothing is moved back).  Samples that come
+//     out of the inverse CDF ascending already (deterministic abscissae) skip the network;
 //   * the merge with the coarse depths (ascending: checked, else the general kernel's full sort runs) is by counting: a
 //     sample from bin b lies between the bin's mid-points, i.e. z[b] <= s <= z[b+2], so its rank among the depths is b + 1 or
 //     b + 2 -- three LDS reads decide and verify (any lane that cannot verify sends the wave to the binary search); an LDS
@@ -462,12 +462,9 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 //     samples fill the remaining slots in order, which each OUTPUT slot works out for itself from a ballot of the depth slots
 //     (no scatter, the row leaves coalesced).  The sorted multiset is what torch.sort returns (T:126 keeps the values only).
 // ---------------------------------------------------------------------------------------------
-#ifndef NF_RS_STOP
-#define NF_RS_STOP 0
-#endif
 #define NF_RS_MAXC 128
 #define NF_RS_MAXF 128
-// floats per wave: cdf[128] | lb[128] (both dead after the inversion: the slot flags alias them) | A[128] B[128] | x[128] / hist[132]
+// floats per wave: cdf[128] + 128 (the slot flags, 256 entries, take both once the table is dead) | A[128] B[128] | x[128] / hist[132]
 #define NF_RS_FLOATS (128 + 128 + 256 + 132)
 #define NF_DPP_XOR1 0xB1                                    // quad_perm:[1,0,3,2]
 #define NF_DPP_XOR2 0x4E                                    // quad_perm:[2,3,0,1]
@@ -603,96 +600,98 @@ constexpr unsigned long long nf_bitclear_mask(int b) {
     for (int l = 0; l < 64; ++l) if (((l >> b) & 1) == 0) m |= 1ull << l;
     return m;
 }
-// v <- lane-mask ? min(v, partner) : max(v, partner); the s_nop covers the VALU-write -> DPP-read hazard the assembler does not see
-#define NF_CE_DPP(V_, CTRL_, MASK_)                                                                                       \
-    do {                                                                                                                  \
-        float mn_, mx_;                                                                                                   \
-        asm("s_nop 1\n\tv_min_f32_dpp %0, %2, %2 " CTRL_ " row_mask:0xf bank_mask:0xf\n\t"                                \
-            "v_max_f32_dpp %1, %2, %2 " CTRL_ " row_mask:0xf bank_mask:0xf" : "=&v"(mn_), "=&v"(mx_) : "v"(V_));          \
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(V_) : "v"(mx_), "v"(mn_), "s"(MASK_));                              \
-    } while (0)
-// the same with row / bank write masks where the lanes that take the minimum are whole banks of whole rows: every instruction writes its
-// part of T_ (the four parts cover the wave), no select.  P_: partner at lane + 4 ("row_shl:4") or lane - 4 ("row_shr:4") or across 8
-#define NF_CE_PART(OP_, T_, V_, P_, ROWS_, BANKS_) "v_" OP_ "_f32_dpp %0, %1, %1 " P_ " row_mask:" ROWS_ " bank_mask:" BANKS_ "\n\t"
-// one DPP level (lane distances 8, 4, 2, 1 as asked) on both registers
-template <int JB, int UB>
-__device__ __forceinline__ void nf_ce_lane(float (&v)[2]) {
-    constexpr unsigned long long M = nf_takemin_mask(JB, UB);
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-        if constexpr (JB == 0) NF_CE_DPP(v[r], "quad_perm:[1,0,3,2]", M);
-        else if constexpr (JB == 1) NF_CE_DPP(v[r], "quad_perm:[2,3,0,1]", M);
-        else if constexpr (JB == 2) {
-            // lane distance 4: banks 0, 2 of a row are the lower lanes (partner at + 4), banks 1, 3 the upper ones (partner at - 4)
-            float t;
-            if constexpr (UB < 0)                           // ascending everywhere
-                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0xf", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0xf", "0xa")
-                    : "=&v"(t) : "v"(v[r]));
-            else if constexpr (UB == 3)                     // direction = lane bit 3: banks 0, 1 ascending, banks 2, 3 descending
-                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0xf", "0x1") NF_CE_PART("max", t, v, "row_shr:4", "0xf", "0x2")
-                    NF_CE_PART("max", t, v, "row_shl:4", "0xf", "0x4") NF_CE_PART("min", t, v, "row_shr:4", "0xf", "0x8") : "=&v"(t) : "v"(v[r]));
-            else if constexpr (UB == 4)                     // direction = lane bit 4: rows 0, 2 ascending, rows 1, 3 descending
-                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0x5", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0x5", "0xa")
-                    NF_CE_PART("max", t, v, "row_shl:4", "0xa", "0x5") NF_CE_PART("min", t, v, "row_shr:4", "0xa", "0xa") : "=&v"(t) : "v"(v[r]));
-            else                                            // direction = lane bit 5: rows 0, 1 ascending, rows 2, 3 descending
-                asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_shl:4", "0x3", "0x5") NF_CE_PART("max", t, v, "row_shr:4", "0x3", "0xa")
-                    NF_CE_PART("max", t, v, "row_shl:4", "0xc", "0x5") NF_CE_PART("min", t, v, "row_shr:4", "0xc", "0xa") : "=&v"(t) : "v"(v[r]));
-            v[r] = t;
-        } else if constexpr (UB < 0) {                      // lane distance 8, ascending everywhere: banks 0, 1 keep the minimum
-            float t;
-            asm("s_nop 1\n\t" NF_CE_PART("min", t, v, "row_ror:8", "0xf", "0x3") NF_CE_PART("max", t, v, "row_ror:8", "0xf", "0xc") : "=&v"(t) : "v"(v[r]));
-            v[r] = t;
-        } else NF_CE_DPP(v[r], "row_ror:8", M);
+// The network runs in a SIGN DOMAIN so that a compare-exchange is ONE instruction: a lane that is to keep the minimum of its pair holds
+// its value as it is, a lane that is to keep the maximum holds it NEGATED; then w <- min(w, -partner(w)) is right for both (the plain
+// lane gets min(x, y), the negated one min(-y, -x) = -max(x, y); DPP takes the negation as a source modifier).  Between two levels the
+// lanes whose role changes flip sign (one v_cndmask with a negated source and a constant lane mask).  Which lanes are plain is compile-time
+// bookkeeping (NfDom), also across the v_permlane swaps, which move values -- and their signs -- between the two registers.
+typedef unsigned long long nf_u64;
+struct NfDom { nf_u64 s0, s1; };                            // lanes of register 0 / 1 that hold plain values
+struct NfSortStep { int kind, jb, ub; };                    // kind 0: DPP level at lane bit jb; 1: between the registers; 2: swap16; 3: swap32
+constexpr NfSortStep NF_SORT_STEPS[] = {
+    // element bits b0..b3 = lane bits 0..3 throughout; (register, lane bit 4, lane bit 5) = (b6, b4, b5) on entry
+    {0, 0, 1},                                              // k = 2 (direction = lane bit 1)
+    {0, 1, 2}, {0, 0, 2},                                   // k = 4
+    {0, 2, 3}, {0, 1, 3}, {0, 0, 3},                        // k = 8
+    {0, 3, 4}, {0, 2, 4}, {0, 1, 4}, {0, 0, 4},             // k = 16 (direction b4 = lane bit 4)
+    {2, 0, 0}, {1, 0, 5},                                   // k = 32: swap16 -> (b4, b6, b5); direction b5 = lane bit 5
+    {0, 3, 5}, {0, 2, 5}, {0, 1, 5}, {0, 0, 5},
+    {3, 0, 0}, {1, 0, 4},                                   // k = 64 (direction b6 = lane bit 4): swap32 -> (b5, b6, b4)
+    {3, 0, 0}, {1, 0, 4},                                   //          swap32 -> (b4, b6, b5)
+    {0, 3, 4}, {0, 2, 4}, {0, 1, 4}, {0, 0, 4},
+    {2, 0, 0}, {1, 0, -1},                                  // k = 128 (ascending): swap16 -> (b6, b4, b5)
+    {3, 0, 0}, {1, 0, -1},                                  //          swap32 -> (b5, b4, b6)
+    {2, 0, 0}, {1, 0, -1},                                  //          swap16 -> (b4, b5, b6)
+    {0, 3, -1}, {0, 2, -1}, {0, 1, -1}, {0, 0, -1},
+};
+constexpr int NF_SORT_NSTEPS = (int)(sizeof(NF_SORT_STEPS) / sizeof(NF_SORT_STEPS[0]));
+constexpr NfDom nf_dom_swapped(NfDom d, int sh) {           // v_permlane{16,32}_swap: (register, lane bit) trade places
+    NfDom o{0, 0};
+    for (int l = 0; l < 64; ++l) {
+        const bool odd = (l & sh) != 0;
+        const nf_u64 b0 = odd ? (d.s1 >> (l - sh)) & 1 : (d.s0 >> l) & 1;
+        const nf_u64 b1 = odd ? (d.s1 >> l) & 1 : (d.s0 >> (l + sh)) & 1;
+        o.s0 |= b0 << l;
+        o.s1 |= b1 << l;
+    }
+    return o;
+}
+constexpr NfDom nf_dom_wanted(NfSortStep st, NfDom cur) {   // the domain step `st` needs on entry (= leaves behind)
+    if (st.kind == 0) { const nf_u64 m = nf_takemin_mask(st.jb, st.ub); return NfDom{m, m}; }
+    if (st.kind == 1) { const nf_u64 up = st.ub < 0 ? ~0ull : nf_bitclear_mask(st.ub); return NfDom{up, ~up}; }
+    return cur;
+}
+constexpr NfDom nf_dom_before(int n) {                      // what the registers hold before step n
+    NfDom d{~0ull, ~0ull};
+    for (int i = 0; i < n; ++i) {
+        d = nf_dom_wanted(NF_SORT_STEPS[i], d);
+        if (NF_SORT_STEPS[i].kind == 2) d = nf_dom_swapped(d, 16);
+        if (NF_SORT_STEPS[i].kind == 3) d = nf_dom_swapped(d, 32);
+    }
+    return d;
+}
+template <nf_u64 F>
+__device__ __forceinline__ void nf_sd_flip(float& w) {
+    if constexpr (F != 0) asm("v_cndmask_b32_e64 %0, %1, -%1, %2" : "=v"(w) : "v"(w), "s"(F));
+}
+// (the s_nop covers the VALU-write -> DPP-read hazard, which the assembler does not see inside an asm statement)
+template <int JB>
+__device__ __forceinline__ void nf_sd_min_dpp(float& w) {
+    float t;
+    if constexpr (JB == 0) asm("s_nop 1\n\tv_min_f32_dpp %0, -%1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(w));
+    else if constexpr (JB == 1) asm("s_nop 1\n\tv_min_f32_dpp %0, -%1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(w));
+    else if constexpr (JB == 2)                             // banks 0, 2 of a row: partner at lane + 4; banks 1, 3: at lane - 4
+        asm("s_nop 1\n\tv_min_f32_dpp %0, -%1, %1 row_shl:4 row_mask:0xf bank_mask:0x5\n\t"
+            "v_min_f32_dpp %0, -%1, %1 row_shr:4 row_mask:0xf bank_mask:0xa" : "=&v"(t) : "v"(w));
+    else asm("s_nop 1\n\tv_min_f32_dpp %0, -%1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(t) : "v"(w));
+    w = t;
+}
+template <int I>
+__device__ __forceinline__ void nf_sort_run(float (&v)[2]) {
+    if constexpr (I < NF_SORT_NSTEPS) {
+        constexpr NfSortStep st = NF_SORT_STEPS[I];
+        constexpr NfDom cur = nf_dom_before(I), want = nf_dom_wanted(st, cur);
+        nf_sd_flip<cur.s0 ^ want.s0>(v[0]);
+        nf_sd_flip<cur.s1 ^ want.s1>(v[1]);
+        if constexpr (st.kind == 0) { nf_sd_min_dpp<st.jb>(v[0]); nf_sd_min_dpp<st.jb>(v[1]); }
+        else if constexpr (st.kind == 1) {
+            float n0, n1;
+            asm("s_nop 1\n\tv_min_f32_e64 %0, %2, -%3\n\tv_min_f32_e64 %1, %3, -%2" : "=&v"(n0), "=&v"(n1) : "v"(v[0]), "v"(v[1]));
+            v[0] = n0; v[1] = n1;
+        } else if constexpr (st.kind == 2) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
+        else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
+        nf_sort_run<I + 1>(v);
+    } else {
+        constexpr NfDom cur = nf_dom_before(NF_SORT_NSTEPS);
+        nf_sd_flip<~cur.s0>(v[0]);                          // back to plain values
+        nf_sd_flip<~cur.s1>(v[1]);
     }
 }
-template <int JB_TOP, int UB>
-__device__ __forceinline__ void nf_ce_lane_down(float (&v)[2]) {
-    if constexpr (JB_TOP >= 3) nf_ce_lane<3, UB>(v);
-    if constexpr (JB_TOP >= 2) nf_ce_lane<2, UB>(v);
-    if constexpr (JB_TOP >= 1) nf_ce_lane<1, UB>(v);
-    nf_ce_lane<0, UB>(v);
-}
-// the element-index bit held by the register index trades places with lane bit 4 (SWAP16) or 5
-template <bool SWAP16>
-__device__ __forceinline__ void nf_sort_swap(float (&v)[2]) {
-    if constexpr (SWAP16) asm("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
-    else asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(v[0]), "+v"(v[1]));
-}
-// compare-exchange between the two registers of a lane; UB: lane bit that holds the direction (-1: ascending everywhere)
-template <int UB>
-__device__ __forceinline__ void nf_ce_regs(float (&v)[2]) {
-    float lo, hi;
-    asm("s_nop 1\n\tv_min_f32 %0, %2, %3\n\tv_max_f32 %1, %2, %3" : "=&v"(lo), "=&v"(hi) : "v"(v[0]), "v"(v[1]));
-    if constexpr (UB < 0) { v[0] = lo; v[1] = hi; }
-    else {
-        constexpr unsigned long long UP = nf_bitclear_mask(UB);
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v[0]) : "v"(hi), "v"(lo), "s"(UP));
-        asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(v[1]) : "v"(lo), "v"(hi), "s"(UP));
-    }
-}
-// Ascending sort.  On exit register r of lane l holds sorted element ((l >> 5) << 6) | (((l >> 4) & 1) << 5) | (r << 4) | (l & 15).
-__device__ __forceinline__ void nf_sort128_regs(float (&v)[2]) {
-    // element bits: b0..b3 = lane bits 0..3 throughout; (register, lane bit 4, lane bit 5) = (b6, b4, b5) on entry
-    nf_ce_lane_down<0, 1>(v);                               // k = 2
-    nf_ce_lane_down<1, 2>(v);                               // k = 4
-    nf_ce_lane_down<2, 3>(v);                               // k = 8
-    nf_ce_lane_down<3, 4>(v);                               // k = 16 (direction: b4 = lane bit 4)
-    nf_sort_swap<true>(v);                                  // k = 32: (b4, b6, b5)
-    nf_ce_regs<5>(v);
-    nf_ce_lane_down<3, 5>(v);
-    nf_sort_swap<false>(v);                                 // k = 64 (direction b6 = lane bit 4): (b5, b6, b4)
-    nf_ce_regs<4>(v);
-    nf_sort_swap<false>(v);                                 //          (b4, b6, b5)
-    nf_ce_regs<4>(v);
-    nf_ce_lane_down<3, 4>(v);
-    nf_sort_swap<true>(v);                                  // k = 128 (ascending): (b6, b4, b5)
-    nf_ce_regs<-1>(v);
-    nf_sort_swap<false>(v);                                 //          (b5, b4, b6)
-    nf_ce_regs<-1>(v);
-    nf_sort_swap<true>(v);                                  //          (b4, b5, b6)
-    nf_ce_regs<-1>(v);
-    nf_ce_lane_down<3, -1>(v);
-}
+// Ascending bitonic sort of 128 values, v[r] = element 64 r + lane on entry.  Exchanges at lane distance 1, 2, 8 are one DPP v_min, at
+// distance 4 two banked ones; at distance 16 / 32 / 64 the element-index bit concerned is first moved into the register index
+// (v_permlane16_swap / v_permlane32_swap; nothing is moved back).  On exit register r of lane l holds sorted element
+// ((l >> 5) << 6) | (((l >> 4) & 1) << 5) | (r << 4) | (l & 15).
+__device__ __forceinline__ void nf_sort128_regs(float (&v)[2]) { nf_sort_run<0>(v); }
 __device__ __forceinline__ int nf_sort128_index(int r, int lane) { return ((lane >> 5) << 6) | (((lane >> 4) & 1) << 5) | (r << 4) | (lane & 15); }
 
 __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __restrict__ zc, const float* __restrict__ wc,
@@ -705,9 +704,8 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     const int64_t ray = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
     if (ray >= n_rays) return;                              // wave-uniform; no block barrier below
     float* cdf = lds[wv];
-    float* lb = cdf + 128;
-    int* flags = reinterpret_cast<int*>(cdf);               // (cdf, lb are dead by then)
-    float* A = lb + 128;                                    // coarse depths (nc)
+    int* flags = reinterpret_cast<int*>(cdf);               // 256 entries: the table (dead by then) and the 128 floats behind it
+    float* A = cdf + 256;                                    // coarse depths (nc)
     float* B = A + 128;                                     // sorted samples (nf)
     float* xs = B + 128;
     int* hist = reinterpret_cast<int*>(xs);                 // (the pdf scratch is dead by then)
@@ -723,9 +721,6 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
         ur[r] = i < nf ? urow[i] : 0.0f;
     }
     nf_build_cdf_wave(wc + ray * nc + 1, nc - 2, cdf, xs, lane);
-#if NF_RS_STOP == 1
-    if (cdf[lane] != 12345.f) return;
-#endif
 #pragma unroll
     for (int r = 0; r < 2; ++r) { const int i = lane + 64 * r; if (i < nc) A[i] = zr[r]; }
     for (int i = lane; i <= nc; i += 64) hist[i] = 0;
@@ -734,15 +729,11 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
         const int i = lane + 64 * r;
-        if (i < n_bins) {
-            const float zn = A[i + 1];
-            lb[i] = nf_mul(0.5f, nf_add(zn, zr[r]));
-            sorted = sorted && zr[r] <= zn;
-        }
+        if (i < n_bins) sorted = sorted && zr[r] <= A[i + 1];
     }
-    nf_wave_sync();
-    // ---- inverse CDF (H:368-387): count = #{cdf <= u} by descent, then the interpolation of nf_invert_cdf ---------------------------
-    float v[2];
+    // ---- inverse CDF (H:368-387): count = #{cdf <= u} by descent, then the interpolation of nf_invert_cdf.  The bin mid-points are formed
+    // from the three depths around the bin, which the rank test below needs anyway (0.5 (z[i+1] + z[i]), T:116, as the general kernel) ------
+    float v[2], a0[2], a1[2], a2[2];
     int below[2];
 #pragma unroll
     for (int r = 0; r < 2; ++r) {                           // (lanes past nf run along on u = 0: no branches, the two descents interleave)
@@ -756,9 +747,11 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
         pos = pos < n_bins ? pos : n_bins;
         const int lo = pos;                                 // torch.searchsorted(cdf, u, right=True)
         const int bl = lo - 1 > 0 ? lo - 1 : 0;
-        const int ab = lo < n_bins - 1 ? lo : n_bins - 1;
+        const int ab = lo < n_bins - 1 ? lo : n_bins - 1;   // bl + 1, or bl at either end of the table
         const float cb = cdf[bl], ca = cdf[ab];
-        const float bb = lb[bl], ba = lb[ab];
+        a0[r] = A[bl]; a1[r] = A[bl + 1]; a2[r] = A[bl + 2 < nc ? bl + 2 : nc - 1];
+        const float bb = nf_mul(0.5f, nf_add(a1[r], a0[r]));
+        const float ba = ab == bl ? bb : nf_mul(0.5f, nf_add(a2[r], a1[r]));
         float den = nf_sub(ca, cb);
         if (den < 1e-5f) den = 1.0f;
         const float t = nf_div(nf_sub(uu, cb), den);
@@ -767,9 +760,6 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
         below[r] = bl;
         if (z_samples && j < nf) z_samples[ray * nf + j] = val;
     }
-#if NF_RS_STOP == 2
-    if (v[0] + v[1] != 12345.f) return;
-#endif
     if (!__all(sorted)) {                                   // coarse depths not ascending (no caller on the hot path produces such a row):
         float* out = A;                                     // sort the concatenation like k_resample_merge does, wave-private (A | B = 256 floats;
                                                             // the depths are in place, the samples follow them directly)
@@ -797,11 +787,9 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
     bool ok = true;
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
-        const int g = below[r] + 1;                         // 1 <= g <= nc - 1
-        const int g2 = g + 1 < nc ? g + 1 : nc - 1;
-        const float a0 = A[g - 1], a1 = A[g], a2 = A[g2];
-        rank[r] = g + (a1 <= v[r] ? 1 : 0);
-        ok = ok && (lane + 64 * r >= nf || (a0 <= v[r] && (g + 1 >= nc || !(a2 <= v[r]))));
+        const int g = below[r] + 1;                         // 1 <= g <= nc - 1; a0, a1, a2 = A[g - 1], A[g], A[min(g + 1, nc - 1)]
+        rank[r] = g + (a1[r] <= v[r] ? 1 : 0);
+        ok = ok && (lane + 64 * r >= nf || (a0[r] <= v[r] && (g + 1 >= nc || !(a2[r] <= v[r]))));
     }
     if (!__all(ok)) {                                       // (degenerate spacing, NaN: the binary search of the round-4 kernel)
 #pragma unroll
@@ -815,9 +803,6 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
 #pragma unroll
     for (int r = 0; r < 2; ++r)
         if (lane + 64 * r < nf) __hip_atomic_fetch_add(&hist[rank[r]], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-#if NF_RS_STOP == 3
-    if (rank[0] + rank[1] != -5) return;
-#endif
     // ---- the samples in ascending order -> B -------------------------------------------------------------------------------------
     {
         const float nx0 = __shfl_down(v[0], 1, 64), nx1 = __shfl_down(v[1], 1, 64), first1 = nf_readlane_f(v[1], 0);
@@ -831,9 +816,6 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
             for (int r = 0; r < 2; ++r) B[nf_sort128_index(r, lane)] = v[r];
         }
     }
-#if NF_RS_STOP == 4
-    if (v[0] + v[1] != 12345.f) return;
-#endif
     // ---- slots of the depths: i + #{samples < z[i]} = i + #{samples of rank <= i} ---------------------------------------------------
     for (int i = lane; i < nt; i += 64) flags[i] = 0;
     nf_wave_sync();
