@@ -97,3 +97,100 @@ extern "C" int nf_adam_step(float* const* params, const float* const* grads, flo
     }
     NF_RETURN_LAUNCH();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The trainer's loss (train_transformed_rays.py:355-387) and its gradients in two launches instead of the ~20 torch launches of
+//   coarse = mse_loss(rgb_coarse, target); fine = mse_loss(rgb_fine, target); code = 0.0005 * torch.norm(latent);
+//   loss = coarse + fine + 10 * code; loss.backward()
+// (two element-wise kernels and a reduction per mse, the norm, the scalar arithmetic, the fills and element-wise kernels of their
+// backward nodes: ~100 us of 4-5 us launches per iteration, 1-2.5 % of a training iteration of the split arithmetics).  The tensors
+// are tiny (2048 x 3 colours, 32 latent values): one workgroup.
+//   forward:  out[0] = loss, out[1] = coarse mse, out[2] = fine mse (0 without a fine map), out[3] = code_weight * ||latent||,
+//             out[4] = coarse + fine, out[5] = -10 log10(max(out[4], 1e-20)) (the PSNR the trainer logs), out[6] = ||latent||
+//   backward: d_rgb = ((2 / n) (rgb - target)) * go   (ATen's mse_loss_backward order),
+//             d_latent = latent * ((go * code_scale * code_weight) / ||latent||), 0 where the norm is 0 (ATen's norm_backward)
+// Sums are accumulated in double (deterministic: fixed assignment of elements to lanes, fixed reduction tree).
+// ---------------------------------------------------------------------------------------------------------------------------------
+#define NF_LOSS_THREADS 1024
+__device__ __forceinline__ double nf_block_sum_f64(double v, double* sh) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long b = __double_as_longlong(v);
+        const unsigned lo = __shfl_xor((unsigned)b, o, 64), hi = __shfl_xor((unsigned)(b >> 32), o, 64);
+        v += __longlong_as_double(((unsigned long long)hi << 32) | lo);
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wv] = v;
+    __syncthreads();
+    double t = 0.0;
+    for (int i = 0; i < NF_LOSS_THREADS / 64; ++i) t += sh[i];
+    return t;
+}
+
+__global__ void __launch_bounds__(NF_LOSS_THREADS) k_train_loss_fwd(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
+                                                                    const float* __restrict__ target, int64_t n,
+                                                                    const float* __restrict__ latent, int n_latent, float code_weight,
+                                                                    float code_scale, float* __restrict__ out) {
+    __shared__ double sh[NF_LOSS_THREADS / 64];
+    double sc = 0.0, sf = 0.0, sl = 0.0;
+    for (int64_t i = threadIdx.x; i < n; i += NF_LOSS_THREADS) {
+        const float t = target[i];
+        const float dc = rgb_c[i] - t;
+        sc += (double)(dc * dc);
+        if (rgb_f) { const float df = rgb_f[i] - t; sf += (double)(df * df); }
+    }
+    if (latent) for (int i = threadIdx.x; i < n_latent; i += NF_LOSS_THREADS) sl += (double)(latent[i] * latent[i]);
+    sc = nf_block_sum_f64(sc, sh);
+    sf = nf_block_sum_f64(sf, sh);
+    sl = nf_block_sum_f64(sl, sh);
+    if (threadIdx.x == 0) {
+        const float coarse = (float)(sc / (double)n), fine = rgb_f ? (float)(sf / (double)n) : 0.0f;
+        const float nrm = (float)sqrt(sl), code = nrm * code_weight;
+        const float mse = rgb_f ? coarse + fine : coarse;
+        out[0] = latent ? mse + code_scale * code : mse;
+        out[1] = coarse; out[2] = fine; out[3] = code; out[4] = mse;
+        out[5] = -10.0f * log10f(fmaxf(mse, 1e-20f));
+        out[6] = nrm;
+    }
+}
+
+__global__ void __launch_bounds__(256) k_train_loss_bwd(const float* __restrict__ rgb_c, const float* __restrict__ rgb_f,
+                                                        const float* __restrict__ target, int64_t n, const float* __restrict__ latent,
+                                                        int n_latent, float code_weight, float code_scale, const float* __restrict__ out,
+                                                        const float* __restrict__ grad_out, float* __restrict__ d_rgb_c,
+                                                        float* __restrict__ d_rgb_f, float* __restrict__ d_latent) {
+    const float go = grad_out[0];
+    const float norm2n = (float)(2.0 / (double)n);
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        const float t = target[i];
+        d_rgb_c[i] = (norm2n * (rgb_c[i] - t)) * go;
+        if (rgb_f) d_rgb_f[i] = (norm2n * (rgb_f[i] - t)) * go;
+    }
+    if (latent && i < n_latent) {
+        const float nrm = out[6];
+        const float g = ((go * code_scale) * code_weight) / nrm;
+        d_latent[i] = nrm == 0.0f ? 0.0f : latent[i] * g;
+    }
+}
+
+extern "C" int nf_train_loss_fwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n_elems, const float* latent,
+                                 int n_latent, float code_weight, float code_scale, float* out7, nf_stream_t stream) {
+    if (!rgb_coarse || !target || !out7 || n_elems <= 0 || n_latent < 0 || (latent && n_latent == 0)) return NF_EINVAL;
+    hipLaunchKernelGGL(k_train_loss_fwd, dim3(1), dim3(NF_LOSS_THREADS), 0, nf_s(stream), rgb_coarse, rgb_fine, target, n_elems, latent,
+                       n_latent, code_weight, code_scale, out7);
+    NF_RETURN_LAUNCH();
+}
+
+extern "C" int nf_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n_elems, const float* latent,
+                                 int n_latent, float code_weight, float code_scale, const float* out7, const float* grad_out,
+                                 float* d_rgb_coarse, float* d_rgb_fine, float* d_latent, nf_stream_t stream) {
+    if (!rgb_coarse || !target || !out7 || !grad_out || !d_rgb_coarse || n_elems <= 0 || (rgb_fine && !d_rgb_fine) || (latent && !d_latent))
+        return NF_EINVAL;
+    const int64_t work = n_elems > n_latent ? n_elems : n_latent;
+    const int64_t grid = (work + 255) / 256;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL(k_train_loss_bwd, dim3((unsigned)grid), dim3(256), 0, nf_s(stream), rgb_coarse, rgb_fine, target, n_elems, latent,
+                       n_latent, code_weight, code_scale, out7, grad_out, d_rgb_coarse, d_rgb_fine, d_latent);
+    NF_RETURN_LAUNCH();
+}

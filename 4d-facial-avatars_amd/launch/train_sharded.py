@@ -126,12 +126,11 @@ def main(argv=None):
         rgb_c, _, _, rgb_f, _, _, _ = nerf.run_one_iter_of_nerf(
             H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="train", encode_position_fn=enc_xyz,
             encode_direction_fn=enc_dir, expressions=expr, background_prior=bg, latent_code=latent)
-        coarse_loss = torch.nn.functional.mse_loss(rgb_c[..., :3], target[..., :3])
-        fine_loss = torch.nn.functional.mse_loss(rgb_f[..., :3], target[..., :3]) if rgb_f is not None else None
-        loss = coarse_loss if fine_loss is None else coarse_loss + fine_loss
-        mse = loss.detach()                                    # read back (a host sync) only on the iterations that log or save
-        code_loss = torch.norm(latent) * 0.0005
-        loss = loss + 10 * code_loss                           # TR:375-387
+        # TR:355-387 (coarse + fine mse, 10 x 0.0005 x ||latent||) and -- in loss.backward() -- the gradients of those nodes: two launches
+        # (nerf.training_loss) instead of ~20; parts = [loss, coarse, fine, code loss, coarse + fine, its PSNR, ||latent||] stay on the device
+        # and are read back (a host sync) only on the iterations that log or save
+        loss, parts = nerf.training_loss(rgb_c[..., :3], rgb_f[..., :3] if rgb_f is not None else None, target[..., :3], latent)
+        coarse_loss, fine_loss, code_loss, mse = parts[1], (parts[2] if rgb_f is not None else None), parts[3], parts[4]
         loss.backward()
         reducer.reduce()
         optimizer.step()
@@ -147,11 +146,11 @@ def main(argv=None):
             nerf.ops.check_f16_range(model_c, model_f, sync_ranks=True)
         if rank == 0:
             # TR:415-424, device-side: the scalars of every iteration, read back together when the iteration prints
-            log.add_scalar("train/code_loss", code_loss.detach(), i)
-            log.add_scalar("train/coarse_loss", coarse_loss.detach(), i)
+            log.add_scalar("train/code_loss", code_loss, i)
+            log.add_scalar("train/coarse_loss", coarse_loss, i)
             if fine_loss is not None:
-                log.add_scalar("train/fine_loss", fine_loss.detach(), i)
-            log.add_scalar("train/psnr", -10.0 * torch.log10(mse.clamp_min(1e-20)), i)
+                log.add_scalar("train/fine_loss", fine_loss, i)
+            log.add_scalar("train/psnr", parts[5], i)
         if rank == 0 and logs_now:
             log.flush()
             print(f"[TRAIN] Iter: {i} Loss: {loss.item():.6f} PSNR: {nerf.mse2psnr(mse.item()):.4f} "

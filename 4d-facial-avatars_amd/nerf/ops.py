@@ -484,6 +484,56 @@ def volume_render_bwd(raw, z, rd, noise, bg, d_rgb, white_background=False):
     return d_raw
 
 
+# ---------------------------------------------------------------------------------------- the trainer's loss (TR:355-387)
+class _TrainingLoss(torch.autograd.Function):
+    """loss = mse(rgb_coarse, target) + mse(rgb_fine, target) + code_scale * code_weight * ||latent||, forward and backward one launch
+    each (nf_train_loss_fwd / nf_train_loss_bwd) instead of the ~20 torch launches of TR:355-387 and their backward nodes."""
+
+    @staticmethod
+    def forward(ctx, rgb_c, rgb_f, target, latent, code_weight, code_scale):
+        dev = H.require_device(rgb_c, rgb_f, target, latent)
+        out = torch.empty((7,), dtype=torch.float32, device=dev)
+        n = rgb_c.numel()
+        with torch.cuda.device(dev):
+            H.check(H.lib().nf_train_loss_fwd(H.ptr(rgb_c), H.ptr(rgb_f), H.ptr(target), n, H.ptr(latent), 0 if latent is None else latent.numel(),
+                                              float(code_weight), float(code_scale), H.ptr(out), H.stream_ptr(dev)), "nf_train_loss_fwd")
+        ctx.save_for_backward(rgb_c, rgb_f, target, latent, out)
+        ctx.consts = (float(code_weight), float(code_scale))
+        parts = out.detach()
+        ctx.mark_non_differentiable(parts)
+        return out[0], parts
+
+    @staticmethod
+    def backward(ctx, go, _go_parts):
+        rgb_c, rgb_f, target, latent, out = ctx.saved_tensors
+        dev = rgb_c.device
+        go = go.to(torch.float32).contiguous()
+        d_c = torch.empty_like(rgb_c)
+        d_f = torch.empty_like(rgb_f) if rgb_f is not None else None
+        d_l = torch.empty_like(latent) if latent is not None else None
+        with torch.cuda.device(dev):
+            H.check(H.lib().nf_train_loss_bwd(H.ptr(rgb_c), H.ptr(rgb_f), H.ptr(target), rgb_c.numel(), H.ptr(latent),
+                                              0 if latent is None else latent.numel(), ctx.consts[0], ctx.consts[1], H.ptr(out), H.ptr(go),
+                                              H.ptr(d_c), H.ptr(d_f), H.ptr(d_l), H.stream_ptr(dev)), "nf_train_loss_bwd")
+        return d_c, d_f, None, d_l, None, None
+
+
+def training_loss(rgb_coarse, rgb_fine, target, latent=None, code_weight: float = 0.0005, code_scale: float = 10.0):
+    """The trainer's loss (TR:355-387) fused: returns (loss, parts) with parts = [loss, coarse mse, fine mse, code loss, coarse + fine,
+    psnr of coarse + fine, ||latent||] (detached, for logging); `loss` is differentiable w.r.t. rgb_coarse, rgb_fine and latent.
+    rgb_fine / latent may be None.  Colour maps and target: the same shape, float32 (made contiguous if they are not)."""
+    rgb_c, tgt = _c(rgb_coarse), _c(target)
+    rgb_f = _c(rgb_fine) if rgb_fine is not None else None
+    lat = _c(latent) if latent is not None else None
+    if tgt.shape != rgb_c.shape or (rgb_f is not None and rgb_f.shape != rgb_c.shape):
+        raise ValueError(f"training_loss: colour maps {tuple(rgb_c.shape)} / {None if rgb_f is None else tuple(rgb_f.shape)} and target "
+                         f"{tuple(tgt.shape)} must have one shape")
+    for t in (rgb_c, rgb_f, tgt, lat):
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("training_loss: float32 tensors only")
+    return _TrainingLoss.apply(rgb_c, rgb_f, tgt, lat, code_weight, code_scale)
+
+
 # ---------------------------------------------------------------------------------------- K6 / K7
 def _u_arg(u: Optional[torch.Tensor], n_rays: int, n_out: int, device):
     if u is None:                                     # det mode (H:357-362): linspace(0,1,n) broadcast over rays

@@ -393,8 +393,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
         out = nerf.run_one_iter_of_nerf(H, W, INTRINSICS, model_c, model_f, ro, rd, opt,
                                         mode="train", encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
                                         expressions=exprs[i], background_prior=bg, latent_code=latent)
-        loss = (torch.nn.functional.mse_loss(out[0], tgt) + torch.nn.functional.mse_loss(out[3], tgt)
-                + 10 * 0.0005 * torch.norm(latent))
+        loss, _ = nerf.training_loss(out[0], out[3], tgt, latent)      # TR:355-387 as the launcher computes it (two launches, fwd + bwd)
         loss.backward()
         reducer.reduce()
         optim.step()

@@ -330,6 +330,18 @@ int nf_adam_step(float* const* params, const float* const* grads, float* const* 
                  const int64_t* numel, int n_tensors, float lr, float beta1, float beta2, float eps, int64_t step,
                  nf_stream_t stream);
 
+/* ---- the trainer's loss and its gradients -- replaces TR:355-387 (coarse = mse_loss(rgb_coarse, target); fine = mse_loss(rgb_fine,
+ *      target); code = code_weight * torch.norm(latent); loss = coarse + fine + code_scale * code) and the backward of those nodes
+ *      (~20 torch launches) by two launches.  n_elems = numel of the colour maps (contiguous f32, same shape as target); rgb_fine and
+ *      latent may be NULL.  out7 = {loss, coarse mse, fine mse, code loss, coarse + fine, -10 log10(coarse + fine), ||latent||}.
+ *      Backward: grad_out = device scalar d(loss); d_rgb = ((2 / n)(rgb - target)) * grad_out (ATen's mse_loss_backward),
+ *      d_latent = latent * (grad_out * code_scale * code_weight / ||latent||), 0 at a zero norm (ATen's norm_backward).            */
+int nf_train_loss_fwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n_elems, const float* latent,
+                      int n_latent, float code_weight, float code_scale, float* out7, nf_stream_t stream);
+int nf_train_loss_bwd(const float* rgb_coarse, const float* rgb_fine, const float* target, int64_t n_elems, const float* latent,
+                      int n_latent, float code_weight, float code_scale, const float* out7, const float* grad_out,
+                      float* d_rgb_coarse, float* d_rgb_fine, float* d_latent, nf_stream_t stream);
+
 /* ---- K7: per-ray ascending sort -- replaces torch.sort(...)[0] at T:126 --------------------------- */
 int nf_sort_rows(const float* in, int64_t n_rows, int n_cols, float* out, nf_stream_t stream);
 

@@ -480,3 +480,39 @@ def test_one_launch_adam_follows_torch_adam(hip_lib, gpu):
         assert float(oc.state[pc[0]]["step"]) == float(ob.state[pb[0]]["step"]) and not oc.state[pc[0]]["step"].is_cuda
         for k, (c_, b) in enumerate(zip(pc, pb)):
             assert float((c_ - b).abs().max() / (b.abs().max() + 1e-12)) < 2e-6, k
+
+
+def test_training_loss_equals_the_torch_expression(hip_lib, gpu):
+    """nerf.training_loss (TR:355-387 in two launches) against the trainer's own torch expression on the device: value and the three
+    gradients, with a fine map and without, a zero latent code (ATen's norm_backward gives 0 there), strided colour maps."""
+    import nerf
+    g = torch.Generator().manual_seed(5)
+    for n, with_fine, zero_lat, strided in ((2048, True, False, False), (2048, True, True, True), (37, False, False, False), (1, True, False, True)):
+        c4 = torch.rand((n, 4), generator=g).to(gpu)
+        f4 = torch.rand((n, 4), generator=g).to(gpu)
+        tgt = torch.rand((n, 3), generator=g).to(gpu)
+        lat = (torch.zeros(32) if zero_lat else 0.1 * torch.randn(32, generator=g)).to(gpu)
+        leaves = [t.clone().requires_grad_(True) for t in (c4, f4, lat)]
+        a, b, l = leaves
+        rc, rf = (a[..., :3], b[..., :3]) if strided else (a[..., :3].contiguous(), b[..., :3].contiguous())
+        want = torch.nn.functional.mse_loss(rc, tgt) + (torch.nn.functional.mse_loss(rf, tgt) if with_fine else 0.0) + 10 * (torch.norm(l) * 0.0005)
+        (3.0 * want).backward()
+        want_g = [x.grad.clone() for x in leaves if x.grad is not None]
+        leaves2 = [t.clone().requires_grad_(True) for t in (c4, f4, lat)]
+        a2, b2, l2 = leaves2
+        rc2, rf2 = (a2[..., :3], b2[..., :3]) if strided else (a2[..., :3].contiguous(), b2[..., :3].contiguous())
+        got, parts = nerf.training_loss(rc2, rf2 if with_fine else None, tgt, l2)
+        assert got.shape == () and not parts.requires_grad and parts.shape == (7,)
+        (3.0 * got).backward()
+        got_g = [x.grad.clone() for x in leaves2 if x.grad is not None]
+        assert abs(float(got) - float(want)) <= 2e-7 * abs(float(want)) + 1e-12
+        p = parts.cpu()
+        assert abs(float(p[0]) - float(got)) == 0.0
+        assert abs(float(p[1]) - float(torch.nn.functional.mse_loss(rc, tgt))) < 1e-7
+        assert abs(float(p[3]) - float(torch.norm(lat) * 0.0005)) < 1e-9
+        assert abs(float(p[5]) - float(-10.0 * torch.log10(p[4].clamp_min(1e-20)))) < 1e-4
+        assert len(got_g) == len(want_g)
+        for x, y in zip(got_g, want_g):
+            assert x.shape == y.shape and torch.allclose(x, y, rtol=2e-6, atol=1e-12), float((x - y).abs().max())
+        if zero_lat:
+            assert float(leaves2[2].grad.abs().max()) == 0.0
