@@ -114,15 +114,40 @@ __global__ void __launch_bounds__(256) k_stream_absmax(NfPackPtrs<N> ptrs, const
     __syncthreads();
     const int span = (n_entries + gridDim.x - 1) / gridDim.x;
     const int e0 = blockIdx.x * span, e1 = e0 + span < n_entries ? e0 + span : n_entries;
-    for (int e = e0 + threadIdx.x; e < e1; e += blockDim.x) {
-        const uint32_t code = table[e], id = code >> 24;
-        if (id == 0xFFu) continue;
-        const float w = fabsf(ptrs.p[id][code & 0xFFFFFFu]);
+    // a thread walks its entries in ascending order, so their layer index never decreases: the running maximum of the current layer stays
+    // in a register and goes to LDS when the layer changes and at the end (one or two LDS atomics per thread instead of one per entry)
+    int cur_l = 0;
+    unsigned cur = 0u;
+    auto take = [&](int e, float w) {
         const int pair = e >> 9;
-        int l = 0;
+        int l = cur_l;
         while (l + 1 < NL && pair >= lp.off[l + 1]) ++l;
-        if (w > 0.0f && w < INFINITY && __float_as_uint(w) > smax[l]) atomicMax(&smax[l], __float_as_uint(w));
+        if (l != cur_l) {
+            if (cur != 0u) atomicMax(&smax[cur_l], cur);
+            cur_l = l;
+            cur = 0u;
+        }
+        w = fabsf(w);
+        if (w > 0.0f && w < INFINITY && __float_as_uint(w) > cur) cur = __float_as_uint(w);
+    };
+    // four entries per trip: the four table reads, then the four gathered weights, are in flight together (two dependent L2 round trips per
+    // trip instead of per entry); 256 workgroups: the kernel's cost was its ~2000 global atomics on eleven addresses (5 ns each), not the reads
+    int e = e0 + threadIdx.x;
+    for (; e + 3 * (int)blockDim.x < e1; e += 4 * blockDim.x) {
+        uint32_t code[4];
+        float w[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) code[q] = table[e + q * blockDim.x];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) w[q] = (code[q] >> 24) == 0xFFu ? 0.0f : ptrs.p[code[q] >> 24][code[q] & 0xFFFFFFu];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) take(e + q * blockDim.x, w[q]);
     }
+    for (; e < e1; e += blockDim.x) {
+        const uint32_t code = table[e], id = code >> 24;
+        if (id != 0xFFu) take(e, ptrs.p[id][code & 0xFFFFFFu]);
+    }
+    if (cur != 0u) atomicMax(&smax[cur_l], cur);
     __syncthreads();
     if (threadIdx.x < NL && smax[threadIdx.x] != 0u) atomicMax(amax_bits + threadIdx.x, smax[threadIdx.x]);
 }
@@ -171,7 +196,7 @@ static inline int nf_pack_split_f16(NfPackTable& cache, Build build, const float
     float* tail = reinterpret_cast<float*>(reinterpret_cast<char*>(stream_out) + (size_t)n_entries * 4);   // 2 blocks x 2 bytes per entry
     hipError_t e = hipMemsetAsync(tail, 0, NF_F16_TAIL_BYTES, nf_s(stream));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((k_stream_absmax<N, TAG, NL>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table, n_entries, lp,
+    hipLaunchKernelGGL((k_stream_absmax<N, TAG, NL>), dim3(256), dim3(256), 0, nf_s(stream), ptrs, table, n_entries, lp,
                        reinterpret_cast<unsigned*>(tail + 2 * NL));
     hipLaunchKernelGGL((k_pack_split_f16<N, TAG, NL>), dim3(1024), dim3(256), 0, nf_s(stream), ptrs, table,
                        reinterpret_cast<_Float16*>(stream_out), n_entries, lp, tail, act_scale);
