@@ -466,8 +466,6 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
 #define NF_RS_MAXF 128
 // floats per wave: cdf[128] + 128 (the slot flags, 256 entries, take both once the table is dead) | A[128] B[128] | x[128] / hist[132]
 #define NF_RS_FLOATS (128 + 128 + 256 + 132)
-#define NF_DPP_XOR1 0xB1                                    // quad_perm:[1,0,3,2]
-#define NF_DPP_XOR2 0x4E                                    // quad_perm:[2,3,0,1]
 #define NF_DPP_ROW_SHL(n) (0x100 + (n))                     // lane i <- lane i + n of its row of 16
 #define NF_DPP_ROW_SHR(n) (0x110 + (n))                     // lane i <- lane i - n
 #define NF_DPP_BCAST15 0x142                                // lane 15 of a row -> every lane of the next row
