@@ -815,6 +815,7 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
         }
     }
     // ---- slots of the depths: i + #{samples < z[i]} = i + #{samples of rank <= i} ---------------------------------------------------
+    nf_wave_sync();                                         // (the flags alias the table as another type: keep the table's reads above this line)
     for (int i = lane; i < nt; i += 64) flags[i] = 0;
     nf_wave_sync();
     {
