@@ -250,18 +250,31 @@ __global__ void __launch_bounds__(256) k_paper_grad_unpack(const float* __restri
     int t = 0;
     while ((int)blockIdx.x >= offs.blk[t + 1]) ++t;                 // uniform
     const int local = ((int)blockIdx.x - offs.blk[t]) * 256 + (int)threadIdx.x;
+    if (t == NF_PAPER_NUM_PARAMS) {
+        // d latent_j = sum_n W0[n][139+j] db0[n] + W3[n][139+j] db3[n]: the one workgroup of this "tensor" used to run 32 threads through
+        // 256 dependent trips -- the longest path of the launch.  All 256 threads: thread (q, j) sums n = 32 q .. 32 q + 31, the eight
+        // partial sums of a j are added in a fixed order (deterministic; the association differs from a single running sum).
+        __shared__ float part[8][32];
+        const int j = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+        const float* w0 = packed + OFF_WC0 + 76 + j;
+        const float* w3 = packed + OFF_WC3 + 76 + j;
+        float v = 0.f;
+#pragma unroll 8
+        for (int n = 32 * q; n < 32 * q + 32; ++n) v += w0[n * NCOND] * sum[CS_L0 + n] + w3[n * NCOND] * sum[CS_L0 + 768 + n];
+        part[q][j] = v;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float r = part[0][j];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) r += part[k][j];
+            grads[offs.off[t] + j] = r;
+        }
+        return;
+    }
     if (local >= offs.off[t + 1] - offs.off[t]) return;
     const int e = offs.off[t] + local;
     {
         float v = 0.f;
-        if (t == NF_PAPER_NUM_PARAMS) {                              // d latent_j = sum_n W0[n][139+j] db0[n] + W3[n][139+j] db3[n]
-            const int j = local;
-            const float* w0 = packed + OFF_WC0 + 76 + j;
-            const float* w3 = packed + OFF_WC3 + 76 + j;
-            for (int n = 0; n < 256; ++n) v += w0[n * NCOND] * sum[CS_L0 + n] + w3[n * NCOND] * sum[CS_L0 + 768 + n];
-            grads[e] = v;
-            return;
-        }
 
         switch (t) {
             case 0: {  // layers_xyz.0.weight [256][171]

@@ -213,15 +213,27 @@ __global__ void __launch_bounds__(256) k_lcode_grad_unpack(const float* __restri
     using namespace nlc;
     const float* cvec = cond + B_CVEC;
     const float* dvec = cond + B_DVEC;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < GRAD_FLOATS; e += gridDim.x * blockDim.x) {
+    if (blockIdx.x == gridDim.x - 1) {
+        // d latent_j = sum_n layer1.weight[n][139 + j] * d b1[n], the last workgroup's job (one thread per j through 256 dependent trips was
+        // the longest path of the launch): thread (q, j) sums n = 32 q .. 32 q + 31, the eight partial sums are added in a fixed order
+        __shared__ float part[8][32];
+        const int j = (int)threadIdx.x & 31, q = (int)threadIdx.x >> 5;
+        const float* w1 = packed + OFF_WC1 + 76 + j;
         float v = 0.f;
-        if (e >= GRAD_PARAM_FLOATS) {                                // d latent_j = sum_n layer1.weight[n][139 + j] * d b1[n]
-            const int j = e - GRAD_PARAM_FLOATS;
-            const float* w1 = packed + OFF_WC1 + 76 + j;
-            for (int n = 0; n < 256; ++n) v += w1[n * 108] * sum[CS_L1 + n];
-            grads[e] = v;
-            continue;
+#pragma unroll 8
+        for (int n = 32 * q; n < 32 * q + 32; ++n) v += w1[n * 108] * sum[CS_L1 + n];
+        part[q][j] = v;
+        __syncthreads();
+        if (threadIdx.x < 32) {
+            float r = part[0][j];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) r += part[k][j];
+            grads[GRAD_PARAM_FLOATS + j] = r;
         }
+        return;
+    }
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < GRAD_PARAM_FLOATS; e += (gridDim.x - 1) * blockDim.x) {
+        float v = 0.f;
         int t = 0;
         while (e >= offs.off[t + 1]) ++t;
         const int local = e - offs.off[t];
@@ -347,7 +359,7 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     NfLcodeGradOffsets offs;
     offs.off[0] = 0;
     for (int i = 0; i < NPARAMS; ++i) offs.off[i + 1] = offs.off[i] + NF_LC_PARAM_NUMEL[i];
-    hipLaunchKernelGGL(k_lcode_grad_unpack, dim3(1024), dim3(256), 0, s, sum, packed, cond, offs, grads);
+    hipLaunchKernelGGL(k_lcode_grad_unpack, dim3(1024 + 1), dim3(256), 0, s, sum, packed, cond, offs, grads);      // + 1: the d-latent workgroup
     NF_RETURN_LAUNCH();
 }
 
