@@ -105,8 +105,27 @@ def build(force: bool = False, verbose: bool = True, _extra=(), _obj="obj", _alw
     return OUT
 
 
+def build_tools(verbose: bool = True):
+    """The stand-alone HIP probes bench.py runs as subprocesses (tools/micro/store_bw: the training kernels' store pattern with
+    nothing else in the way).  Binaries stay beside their source (git-ignored; they travel with the push like the library)."""
+    micro = os.path.normpath(os.path.join(HERE, "..", "tools", "micro"))
+    built = []
+    for name in ("store_bw",):
+        src, exe = os.path.join(micro, name + ".hip"), os.path.join(micro, name)
+        if os.path.exists(exe) and os.path.getmtime(exe) > os.path.getmtime(src):
+            continue
+        r = subprocess.run([_hipcc(), "--offload-arch=gfx950", "-O2", "-Wno-unused-result", "-o", exe, src], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n" + r.stdout.decode())
+        built.append(exe)
+        if verbose:
+            print("built", exe)
+    return built
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "--variant":          # python build.py --variant NAME -DFOO=1 ...
         print(build_variant(sys.argv[2], sys.argv[3:]))
     else:
         build(force="--force" in sys.argv)
+        build_tools()

@@ -92,6 +92,9 @@ static int nfb_launch(const void* packed_bf16, const float* cond, const float* r
     if (n_points == 0) return 0;
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    // the save path addresses a section with 32-bit byte offsets (up to 1 KiB per padded point): larger launches would wrap the
+    // buffer descriptor to an empty range and drop every save without an error
+    if (saved && nfb_pad32(n_points) >= ((int64_t)1 << 22)) return NF_EINVAL;
     if (saved) return nfb_launch_train(reinterpret_cast<const char*>(packed_bf16), cond, ro, rd, rd_view ? rd_view : rd, z, n_points,
                                        n_samples, raw, saved, (unsigned)grid, stream);
     hipLaunchKernelGGL(k_paper_mlp_fwd_bf16, dim3((unsigned)grid), dim3(256), 0, nf_s(stream),

@@ -367,7 +367,7 @@ static int nf_bwd_impl(const float* packed, const float* packed_t, const void* p
     if ((packed_t_bf16 || packed_t_f16) && !split_dw && !saved_f32) return NF_EINVAL;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_paper_bwd_workspace_floats(n_points)) return NF_EINVAL;
-    if (n_points >= ((int64_t)1 << 22)) return NF_EINVAL;                // as the training forward: 32-bit byte offsets into a dZ section
+    if (((n_points + 31) & ~(int64_t)31) >= ((int64_t)1 << 22)) return NF_EINVAL;   // as the training forward: 32-bit byte offsets into a (32-padded) section
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return (int)e;

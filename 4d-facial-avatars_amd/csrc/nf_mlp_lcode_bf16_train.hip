@@ -20,6 +20,7 @@ extern "C" int nf_lcode_mlp_fwd_train_bf16(const void* packed_bf16, const float*
     if (n_points == 0) return 0;
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    if (((n_points + 31) & ~(int64_t)31) >= ((int64_t)1 << 22)) return NF_EINVAL;   // 32-bit byte offsets into a (32-padded) saved section
     hipLaunchKernelGGL(k_lcode_mlp_fwd_bf16_train, dim3((unsigned)grid), dim3(256), 0, nf_s(stream),
                        reinterpret_cast<const char*>(packed_bf16), cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     NF_RETURN_LAUNCH();

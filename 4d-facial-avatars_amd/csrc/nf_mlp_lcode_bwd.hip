@@ -308,7 +308,7 @@ static int nf_lcode_bwd_impl(const float* packed, const float* packed_t, const v
     const bool split = packed_t_bf16 != nullptr || packed_t_f16 != nullptr;
     const int64_t n_points = n_rays * n_samples;
     if (workspace_floats < nf_lcode_bwd_workspace_floats(n_points)) return NF_EINVAL;
-    if (n_points >= ((int64_t)1 << 22)) return NF_EINVAL;                // 32-bit byte offsets into a dZ section (exact-f32 chain)
+    if (((n_points + 31) & ~(int64_t)31) >= ((int64_t)1 << 22)) return NF_EINVAL;   // 32-bit byte offsets into a (32-padded) dZ / saved section
     int64_t pps; int ns;
     NfDwGroupSet gset;
     NfReduceAlt alt;

@@ -44,6 +44,7 @@ extern "C" int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* c
     if (n_points == 0) return 0;
     const int64_t grid = (n_points + 127) / 128;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    if (((n_points + 31) & ~(int64_t)31) >= ((int64_t)1 << 22)) return NF_EINVAL;   // 32-bit byte offsets into a (32-padded) saved section
     return nfh_lcode_launch_train(reinterpret_cast<const char*>(packed_f16), cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw,
                                   saved, (unsigned)grid, stream);
 }

@@ -359,6 +359,17 @@ extern "C" int nf_sample_pdf(const float* bins, const float* weights, const floa
 // K7: ascending bitonic sort of one row per wave in wave-private LDS (n padded to a power of two
 // with +inf).  Values only (the reference discards torch.sort's indices, T:126).
 // ---------------------------------------------------------------------------------------------
+// The order of torch.sort: ascending, NaNs after +inf.  A plain `a > b` is no order once a NaN is present (every comparison with it is
+// false): a compare-exchange network then leaves the row unsorted AND lets the +inf padding of the power-of-two tail migrate below n,
+// pushing NaNs out of the part that is written back.  nf_sort_gt is a total order: finite / inf values by value (ties and -0 / +0
+// exactly as `a > b` treats them), then NaNs (all equal), then the padding entries (NF_SORT_PAD: a NaN payload no arithmetic produces).
+#define NF_SORT_PAD __int_as_float(0x7fffffff)
+__device__ __forceinline__ int nf_sort_class(float x) {
+    const int b = __float_as_int(x);
+    return (b & 0x7fffffff) > 0x7f800000 ? (b == 0x7fffffff ? 2 : 1) : 0;
+}
+__device__ __forceinline__ bool nf_sort_gt(float a, float b) { return a > b || nf_sort_class(a) > nf_sort_class(b); }
+
 __device__ __forceinline__ void nf_bitonic_sort(float* buf, int n_pow2) {
     const int lane = nf_lane();
     for (int k = 2; k <= n_pow2; k <<= 1) {
@@ -368,7 +379,7 @@ __device__ __forceinline__ void nf_bitonic_sort(float* buf, int n_pow2) {
                 const int p = i | j;
                 const bool up = (i & k) == 0;
                 const float a = buf[i], b = buf[p];
-                if ((a > b) == up) { buf[i] = b; buf[p] = a; }
+                if (nf_sort_gt(a, b) == up) { buf[i] = b; buf[p] = a; }
             }
             __syncthreads();
         }
@@ -384,7 +395,7 @@ __global__ void __launch_bounds__(256) k_sort_rows(const float* __restrict__ in,
     const int64_t row = (int64_t)blockIdx.x * NF_RAYS_PER_BLOCK + wv;
     const bool on = row < n_rows;
     const int np2 = nf_next_pow2(n_cols);
-    for (int i = lane; i < np2; i += 64) lds[wv][i] = (on && i < n_cols) ? in[row * n_cols + i] : INFINITY;
+    for (int i = lane; i < np2; i += 64) lds[wv][i] = (on && i < n_cols) ? in[row * n_cols + i] : NF_SORT_PAD;
     __syncthreads();
     nf_bitonic_sort(lds[wv], np2);
     if (on) for (int i = lane; i < n_cols; i += 64) out[row * n_cols + i] = lds[wv][i];
@@ -424,7 +435,7 @@ __global__ void __launch_bounds__(256) k_resample_merge(const float* __restrict_
             if (i < n_bins) lb[i] = nf_mul(0.5f, nf_add(zc[ray * nc + i + 1], zi));
         }
     }
-    for (int i = nt + lane; i < np2; i += 64) srt[i] = INFINITY;
+    for (int i = nt + lane; i < np2; i += 64) srt[i] = NF_SORT_PAD;
     __syncthreads();
     if (on)
         for (int j = lane; j < nf; j += 64) {
@@ -762,14 +773,17 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
         below[r] = bl;
         if (z_samples && j < nf) z_samples[ray * nf + j] = val;
     }
-    if (!__all(sorted)) {                                   // coarse depths not ascending (no caller on the hot path produces such a row):
+    // NaN samples (NaN weights / u, a diverged model) must survive as NaNs: the v_min-only register network below returns the non-NaN
+    // operand of a compare-exchange, so such rows take the compare-swap path too (a total order with NaNs last, like torch.sort)
+    const bool has_nan = __any((v[0] != v[0]) || (v[1] != v[1]));
+    if (has_nan || !__all(sorted)) {                        // coarse depths not ascending (no caller on the hot path produces such a row):
         float* out = A;                                     // sort the concatenation like k_resample_merge does, wave-private (A | B = 256 floats;
                                                             // the depths are in place, the samples follow them directly)
         const int np2 = nf_next_pow2(nt);
         nf_wave_sync();
 #pragma unroll
         for (int r = 0; r < 2; ++r) { const int j = lane + 64 * r; if (j < nf) out[nc + j] = v[r]; }
-        for (int i = nt + lane; i < np2; i += 64) out[i] = INFINITY;
+        for (int i = nt + lane; i < np2; i += 64) out[i] = NF_SORT_PAD;
         nf_wave_sync();
         for (int k = 2; k <= np2; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
@@ -777,7 +791,7 @@ __global__ void __launch_bounds__(256) k_resample_merge_small(const float* __res
                     const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), q = i | j;
                     const bool up = (i & k) == 0;
                     const float a = out[i], b = out[q];
-                    if ((a > b) == up) { out[i] = b; out[q] = a; }
+                    if (nf_sort_gt(a, b) == up) { out[i] = b; out[q] = a; }
                 }
                 nf_wave_sync();
             }

@@ -27,15 +27,28 @@ from nerf import ops
 class PngWriter:
     """Asynchronous PNG output: the uint8 image leaves the device by a non-blocking copy into pinned memory and is encoded
     on a worker thread (zlib releases the GIL), so that frame i+1 renders while frame i is compressed and written -- the
-    8-GPU sequence render is not bound by the host (the reference encodes synchronously through matplotlib, EV:42-51)."""
+    8-GPU sequence render is not bound by the host (the reference encodes synchronously through matplotlib, EV:42-51).
+    Pinned staging buffers are recycled (one hipHostMalloc per image shape and in-flight job, not one per frame: a pinned
+    allocation costs the render loop about a millisecond of host time and a device-wide synchronisation)."""
 
-    def __init__(self, workers: int = 2):
+    def __init__(self, workers: int = 4):
+        import threading
         from concurrent.futures import ThreadPoolExecutor
         self.pool = ThreadPoolExecutor(max_workers=workers)
         self.jobs = []
+        self.free = {}                                         # (shape) -> idle pinned buffers
+        self.lock = threading.Lock()
+
+    def _staging(self, shape):
+        with self.lock:
+            idle = self.free.get(shape)
+            if idle:
+                return idle.pop()
+        return torch.empty(shape, dtype=torch.uint8).pin_memory()
 
     def submit(self, img_u8: torch.Tensor, path: str) -> None:
-        host = torch.empty(img_u8.shape, dtype=torch.uint8).pin_memory()
+        shape = tuple(img_u8.shape)
+        host = self._staging(shape)
         host.copy_(img_u8, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(img_u8.device))
@@ -44,6 +57,8 @@ class PngWriter:
             from PIL import Image
             ev.synchronize()
             Image.fromarray(host.numpy()).save(path)
+            with self.lock:
+                self.free.setdefault(shape, []).append(host)
         self.jobs.append(self.pool.submit(work))
         self.jobs = [j for j in self.jobs if not j.done() or j.result() is not None]      # surfaces worker exceptions
 
@@ -68,6 +83,7 @@ def jet_u8(x):
 def main(argv=None):
     keep = nerf.get_mlp_precision()          # the precision switch is process-global: leave it as the caller had it
     try:
+        main.last_stats = None
         return _main(argv)
     finally:
         nerf.set_mlp_precision(keep)
@@ -185,11 +201,17 @@ def _main(argv=None):
         ev1.record()
         marks.append((ev0, ev1))
     torch.cuda.synchronize()
+    t_gpu_done = time.time()
     writer.close()
+    t_end = time.time()
     times = [a.elapsed_time(b) * 1e-3 for a, b in marks]
+    # what the loop cost (rank-local): GPU seconds per frame from the HIP events, wall of the loop including the PNG tail
+    main.last_stats = {"frames": len(times), "gpu_s_per_frame": sum(times) / len(times) if times else None,
+                       "gpu_s_total": sum(times), "wall_s": t_end - t_start, "wall_s_until_gpu_idle": t_gpu_done - t_start,
+                       "frames_s": len(times) / (t_end - t_start) if times else None}
     if times:
         print(f"[rank {rank}] rendered {len(times)} of {n} frames, avg time per image: {sum(times) / len(times):.3f} s "
-              f"(GPU time per frame; wall {time.time() - t_start:.1f} s including PNG output)")
+              f"(GPU time per frame; wall {t_end - t_start:.1f} s including PNG output)")
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
     return mine

@@ -124,6 +124,9 @@ _PROTOTYPES = {
 }
 # entry points that later ABI revisions add; absent symbols only fail when called
 _OPTIONAL = set()
+# the revision of include/nerface_hip.h these prototypes were written for (nf_abi_version() of the library must equal it: a stale
+# .so with other signatures would take e.g. a stream pointer as `saved_f32` without any error)
+ABI_VERSION = 2
 
 
 def lib_path() -> str:
@@ -151,6 +154,9 @@ def lib():
                     continue
                 raise RuntimeError(f"libnerface_hip.so does not export {name}; rebuild it")
             fn.restype, fn.argtypes = res, args
+        if handle.nf_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"libnerface_hip.so at {_LIB_PATH} has ABI revision {handle.nf_abi_version()}, this binding needs {ABI_VERSION}: "
+                               "rebuild it (python 4d-facial-avatars_amd/build.py --force)")
         _lib = handle
     return _lib
 

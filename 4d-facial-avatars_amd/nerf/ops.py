@@ -522,15 +522,15 @@ def training_loss(rgb_coarse, rgb_fine, target, latent=None, code_weight: float 
     """The trainer's loss (TR:355-387) fused: returns (loss, parts) with parts = [loss, coarse mse, fine mse, code loss, coarse + fine,
     psnr of coarse + fine, ||latent||] (detached, for logging); `loss` is differentiable w.r.t. rgb_coarse, rgb_fine and latent.
     rgb_fine / latent may be None.  Colour maps and target: the same shape, float32 (made contiguous if they are not)."""
+    for t in (rgb_coarse, rgb_fine, target, latent):                     # before _c(): a float64 map must not be down-cast silently
+        if t is not None and t.dtype != torch.float32:
+            raise TypeError("training_loss: float32 tensors only")
     rgb_c, tgt = _c(rgb_coarse), _c(target)
     rgb_f = _c(rgb_fine) if rgb_fine is not None else None
     lat = _c(latent) if latent is not None else None
     if tgt.shape != rgb_c.shape or (rgb_f is not None and rgb_f.shape != rgb_c.shape):
         raise ValueError(f"training_loss: colour maps {tuple(rgb_c.shape)} / {None if rgb_f is None else tuple(rgb_f.shape)} and target "
                          f"{tuple(tgt.shape)} must have one shape")
-    for t in (rgb_c, rgb_f, tgt, lat):
-        if t is not None and t.dtype != torch.float32:
-            raise TypeError("training_loss: float32 tensors only")
     return _TrainingLoss.apply(rgb_c, rgb_f, tgt, lat, code_weight, code_scale)
 
 

@@ -441,7 +441,7 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
                                  "ranks_seen": allreduce["ranks_seen"], "allreduce_us": allreduce["allreduce_us"],
                                  "bytes_allreduced": allreduce["bytes_allreduced"], "mlp_precision": args.precision,
                                  "hbm_fill_gbs": result["config"]["device"].get("hbm_fill_gbs")}
-            print(json.dumps(result), flush=True)
+            globals()["emit"](result)
     if dist is not None:
         dist.barrier()
         if emit:
@@ -519,18 +519,38 @@ def bench_tiny(dev, steps=20):
 
 
 def cpu_baseline_tiny(params, pose, focal, reps=3):
-    """configs[0] on the host: the CPU oracle of tiny_nerf (TN:111-159) on the same weights / pose (the reference's own
-    CPU-runnable case)."""
+    """configs[0] on the host, kind "reference": the UNMODIFIED tiny_nerf.py's own `run_one_iter_of_tinynerf` (TN:111-159) with its
+    own VeryTinyNerfModel on the same weights / pose (imported through oracle/ref_import.import_reference_tiny: live tree or the
+    travelling archive); the oracle port of the same image beside it.  kind "port" only where the reference is absent."""
     from oracle import nerface_oracle as O
+    from oracle import ref_import as RI
     torch.set_num_threads(min(os.cpu_count() or 1, 16))                 # 131k points x 128 features: more threads only add overhead
     with torch.no_grad():
         O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10)
         t0 = time.perf_counter()
         for _ in range(reps):
             O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=torch.zeros(64, 64, 32))
-        cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
-    return {"value": 4096 / (cpu_ms * 1e-3), "unit": "rays/s", "ms_per_image": cpu_ms, "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} whole 64x64x32 images"}
+        port_ms = 1e3 * (time.perf_counter() - t0) / reps
+    port = {"value": 4096 / (port_ms * 1e-3), "unit": "rays/s", "ms_per_image": port_ms, "kind": "port"}
+    if RI.reference_importable():
+        try:
+            ref = RI.import_reference()
+            TN = RI.import_reference_tiny()
+            tm = TN.VeryTinyNerfModel(num_encoding_functions=10)
+            tm.load_state_dict(params)
+            enc = ref.positional_encoding                                  # what the script passes (TN:230, 288)
+            with torch.no_grad():
+                TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, enc, ref.get_minibatches, 16384, tm, 10)
+                t0 = time.perf_counter()
+                for _ in range(reps):
+                    TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, enc, ref.get_minibatches, 16384, tm, 10)
+                cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
+            return {"value": 4096 / (cpu_ms * 1e-3), "unit": "rays/s", "ms_per_image": cpu_ms, "cores": torch.get_num_threads(),
+                    "kind": "reference", "sample": f"{reps} whole 64x64x32 images, UNMODIFIED tiny_nerf.run_one_iter_of_tinynerf (torch-CPU fp32)",
+                    "imported_from": RI.reference_kind(), "port": port}
+        except Exception as e:
+            port["reference_error"] = repr(e)
+    return {**port, "cores": torch.get_num_threads(), "sample": f"{reps} whole 64x64x32 images (oracle port)"}
 
 
 def eager_rocm_baseline(dev, n_rays=32768, chunk=8192):
@@ -574,6 +594,95 @@ def eager_rocm_baseline(dev, n_rays=32768, chunk=8192):
     return {"value": n_rays / dt, "unit": "rays/s", "kind": "port", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
             "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, ray chunk {chunk}, oracle ops on {torch.cuda.get_device_name(dev)}, {dt * 1e3:.0f} ms",
             "note": "stock PyTorch-ROCm eager execution of the reference algorithm on the same GPU; the reference's own scripts cannot run on this box"}
+
+
+def eager_rocm_reference(dev):
+    """The same-GPU denominator of north_star ("the reference PyTorch-CUDA rays/sec"): the UNMODIFIED reference's `get_ray_bundle`
+    (H:68-123) + `run_one_iter_of_nerf` (T:165-290, mode="validation") with both models and every tensor on this MI355X, executed by
+    stock PyTorch-ROCm eager -- one whole 512x512 frame, 64+128 samples, chunksize 65536 and perturb on as shipped (CFG:156), after a
+    one-chunk warm-up, synchronised timing.  A baseline leg: imported out of /root/reference or oracle/_ref/nerface_ref.zip, never
+    part of the product or of the timed region of the headline."""
+    from oracle import cases as C
+    from oracle import make_golden as MG
+    from oracle import nerface_oracle as O
+    from oracle import ref_import as RI
+    ref = RI.import_reference()                                             # (raises when the reference did not travel)
+    c = C.build_case("eval_det_64_128")
+    mc, mf = MG.ref_model(ref, c["p_coarse"]).to(dev).eval(), MG.ref_model(ref, c["p_fine"]).to(dev).eval()
+    opt = MG.ref_options(ref, N_COARSE, N_FINE, True, 0.0)                  # chunksize 65536, perturb on, noise 0: the shipped validation block
+    enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
+    enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
+    pose = O.frame_pose(c["frame"])[:3, :4].to(dev)
+    bg = O.synthetic_image(H, W, 7).reshape(-1, 3).to(dev)
+    expr, lat = c["expr"].to(dev), c["latent"].to(dev)
+
+    def frame(rows):
+        with torch.no_grad():
+            ro, rd = ref.get_ray_bundle(H, W, INTRINSICS, pose)
+            ro, rd = ro[:rows], rd[:rows]
+            return ref.run_one_iter_of_nerf(rows, W, INTRINSICS, mc, mf, ro, rd, opt, mode="validation", encode_position_fn=enc_xyz,
+                                            encode_direction_fn=enc_dir, expressions=expr, background_prior=bg[:rows * W], latent_code=lat)
+    frame(CHUNK // W)                                                       # warm-up: one 65536-ray chunk (rocBLAS / hipBLASLt plans, allocator)
+    torch.cuda.synchronize()
+    peak0 = torch.cuda.max_memory_allocated(dev)
+    t0 = time.perf_counter()
+    out = frame(H)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
+    return {"value": H * W / dt, "unit": "rays/s", "kind": "reference", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
+            "sample": f"one whole 512x512 frame ({H * W} rays), 64+128 samples, chunksize 65536, perturb on, UNMODIFIED reference "
+                      f"get_ray_bundle + run_one_iter_of_nerf on {torch.cuda.get_device_name(dev)} (PyTorch-ROCm eager), {dt * 1e3:.0f} ms",
+            "imported_from": RI.reference_kind(), "peak_device_bytes": int(max(peak0, torch.cuda.max_memory_allocated(dev)))}
+
+
+def launcher_eval_leg(dev, model_c, model_f, n_frames=32):
+    """configs[3] readiness: launch/eval_sharded.py itself on a synthetic 512x512 sequence of n_frames test frames in the on-disk
+    format (tools/make_synthetic_dataset.py), one GPU, f32, PNG + normal-map output -- frames/s of the loop's WALL time (including
+    the PNG tail) against the GPU seconds per frame its HIP events measure: wall / GPU ~ 1 means the sequence render is not
+    host-bound (EV:392-498 with EV:42-51, 469-488 moved to the device / to worker threads)."""
+    import shutil
+    import tempfile
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import make_synthetic_dataset as MS
+    from launch import eval_sharded
+    base = tempfile.mkdtemp(prefix="nf_launcher_")
+    try:
+        data = MS.write(os.path.join(base, "data"), size=H, n_train=2, n_val=1, n_test=n_frames)
+        cfg = MS.config(data, os.path.join(base, "logs"))
+        cfg["nerf"]["validation"].update(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=CHUNK)
+        cfg_path = os.path.join(base, "config.yml")
+        with open(cfg_path, "w") as f:
+            yaml.safe_dump(cfg, f)
+        ck_path = os.path.join(base, "ck.ckpt")
+        torch.save({"model_coarse_state_dict": model_c.state_dict(), "model_fine_state_dict": model_f.state_dict(),
+                    "latent_codes": 0.1 * torch.randn(2, 32), "background": None}, ck_path)
+        out = os.path.join(base, "render")
+        eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out, "--save-normals", "--precision", "f32"])
+        st = dict(eval_sharded.main.last_stats)
+        n_png = len([f for f in os.listdir(out) if f.endswith(".png")])
+        assert n_png == n_frames, (n_png, n_frames)
+        return {"launcher_eval_frames_s": st["frames_s"], "launcher_gpu_s_per_frame": st["gpu_s_per_frame"],
+                "launcher_wall_over_gpu": st["wall_s"] / st["gpu_s_total"], "frames": st["frames"], "wall_s": st["wall_s"],
+                "wall_s_until_gpu_idle": st["wall_s_until_gpu_idle"],
+                "what": f"launch/eval_sharded.py, {n_frames} test frames 512x512, 64+128, f32, PNG + normals written, one GPU; wall includes the PNG tail"}
+    finally:
+        shutil.rmtree(base, ignore_errors=True)
+
+
+def pattern_store_probe():
+    """tools/micro/store_bw: the training kernels' store pattern (256 persistent workgroups, 1 KiB per instruction, nine 256 MiB
+    planes = 2.4 GB, nt and default policy) with nothing else in the way -- separates a box whose memory system takes these
+    streams badly from a good one, which the sequential fill probe does not."""
+    exe = os.path.join(ROOT, "tools", "micro", "store_bw")
+    if not os.path.exists(exe):
+        return {"error": "tools/micro/store_bw not built (__graft_entry__.build())"}
+    try:
+        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+        return json.loads(r.stdout.strip().splitlines()[-1])
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def device_info(dev):
@@ -738,9 +847,8 @@ def pmc_traffic(precision, timeout=240):
 
 
 def pmc_train_traffic(train, timeout=300):
-    """Fill `traffic` of every training kernel of the `train` object (all arithmetics in one pair of PMC passes).  The training
-    kernels read with 16-byte lanes (dwordx4 / LDS-DMA), the access width for which MI355X_MICROARCH.md calibrates FETCH_SIZE at
-    half the bytes: `traffic` = 2 x fetch + write, the raw counters are kept beside it."""
+    """Fill `traffic` of every training kernel of the `train` object (all arithmetics in one pair of PMC passes): raw FETCH_SIZE +
+    WRITE_SIZE bytes per launch."""
     precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
     names = [k for p in precs for k, _ in TRAIN_KERNELS[p]]
     got, detail = pmc_kernel_bytes("pmc_train_launch.py", precs, names, timeout)
@@ -750,11 +858,12 @@ def pmc_train_traffic(train, timeout=300):
                 obj["traffic_detail"] = detail
                 continue
             f, w = got[kname]["fetch_bytes"], got[kname]["write_bytes"]
-            # (round 4: the split weight-gradient kernels DMA half of their operands 16 B per lane -- the forward's fragment stream -- and the
-            # raw FETCH_SIZE of the whole kernel is 0.55 of its algorithmic bytes: the x2 calibration applies to them as well)
-            wide = True
-            obj["traffic"] = (2 * f if wide else f) + w
-            obj["traffic_detail"] = {"fetch_bytes_raw": f, "write_bytes": w, "fetch_correction": "x2 (16 B/lane reads)" if wide else "none (4 B/lane reads)",
+            # `traffic` = the RAW counters (FETCH_SIZE + WRITE_SIZE, KiB x 1024): an independent measurement.  The guide's gfx950 note
+            # (FETCH_SIZE under-counts 16 B/lane reads by 2x) applies to part of these kernels' reads only (the LDS-DMA'd fragment
+            # streams; dZ / d_raw rows are 4 B/lane loads), so the x2 figure is kept beside it as an ESTIMATE of the upper bound, not
+            # as the measurement (calibrating the counter against the expected bytes is no measurement)
+            obj["traffic"] = f + w
+            obj["traffic_detail"] = {"fetch_bytes_raw": f, "write_bytes": w, "traffic_if_all_fetches_undercount_2x_estimate": 2 * f + w,
                                      "algorithmic_bytes_per_launch": obj["algorithmic_hbm_bytes_per_point"] * 2048 * 128, **detail}
 
 
@@ -793,6 +902,17 @@ def pmc_train_clocks(train, timeout=300):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def self_launch(n):
+    """Re-exec this command under torch.distributed.run with n ranks on this node; returns the launcher's exit code."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -812,9 +932,17 @@ def main():
                     help="eval (default) = BASELINE.json's metric; train = configs[2]/[4] as the headline: 2048 rays/iter, 64+64, fwd+bwd+Adam")
     ap.add_argument("--cpu-rays", type=int, default=12288)
     ap.add_argument("--train-steps", type=int, default=40, help="iterations of the `train` object of the eval line")
+    ap.add_argument("--launcher-frames", type=int, default=32, help="frames of the launch/eval_sharded.py throughput leg")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) with the
+        # same argv; the children see WORLD_SIZE and take the branch below.  --gpus 1 stays in-process.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree "
+                         "(the line reports n_gpus = ranks that ran)")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -984,8 +1112,9 @@ def main():
                                 "constant input columns (expression, latent, PE(near), PE(far)) into bias vectors and issues 999,936 MFMA FLOPs per "
                                 "point.  frac = executed_tflops / peak: the physical busy fraction of the fp32 matrix pipe at the NOMINAL 2.4 GHz clock "
                                 "(<= 1); frac_algorithmic = achieved / peak may exceed 1 (the folded 9 % cost no matrix cycles); "
-                                "frac_at_sustained_clock prices the executed FLOPs against 256 CUs x 256 FLOP/clk x the clock this kernel actually "
-                                "held (GRBM_GUI_ACTIVE / dispatch time, a PMC pass of this run)"}}
+                                "frac_at_sustained_clock = executed FLOPs / (busy cycles of ONE PMC dispatch x 256 CUs x 256 FLOP/clk): cycles and "
+                                "FLOPs of the same launch (GRBM_GUI_ACTIVE, a PMC pass of this run)",
+                        "note_short": "frac = issued MFMA FLOPs (999,936/pt) / peak at 2.4 GHz; frac_algorithmic counts 1,100,032/pt"}}
         for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
             exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms[prec] * 1e-3) / 1e12
@@ -1008,9 +1137,12 @@ def main():
             mhz, clk_detail = pmc_sustained_clock("f32")
             objs["f32"]["sustained_clock_mhz"], objs["f32"]["sustained_clock_detail"] = mhz, clk_detail
             if mhz:
-                peak_at = line["config"]["device"]["compute_units"] * 256 * mhz * 1e6 / 1e12
-                objs["f32"]["peak_at_sustained_clock_tflops"] = peak_at
-                objs["f32"]["frac_at_sustained_clock"] = objs["f32"]["executed_tflops"] / peak_at
+                # ONE pass, one dispatch: executed FLOPs of the launch / (busy cycles of that dispatch x 256 CUs x 256 FLOP per clock) --
+                # no HIP-event time of another run enters (the round-4 figure mixed two passes)
+                cus = line["config"]["device"]["compute_units"]
+                cyc = clk_detail["busy_cycles_raw_median"] / clk_detail["xcd_sum_divisor"]
+                objs["f32"]["peak_at_sustained_clock_tflops"] = cus * 256 * mhz * 1e6 / 1e12
+                objs["f32"]["frac_at_sustained_clock"] = float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (cyc * cus * 256)
         line["roofline"] = objs[args.precision]
         for other in others:
             line.setdefault(key_of[other], {})["roofline"] = objs[other]
@@ -1024,27 +1156,101 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             try:
                 torch.cuda.empty_cache()
-                line["eager_rocm"] = eager_rocm_baseline(dev)
-                line["eager_rocm"]["product_over_eager"] = line["value"] / line["eager_rocm"]["value"]
+                port = eager_rocm_baseline(dev)                   # the oracle's ops on the GPU (kind "port"), kept beside the real thing
             except Exception as e:                                # an extra must never cost the headline
-                line["eager_rocm"] = {"error": repr(e)}
+                port = {"error": repr(e)}
+            try:
+                torch.cuda.empty_cache()
+                line["eager_rocm"] = eager_rocm_reference(dev)    # raises where neither /root/reference nor oracle/_ref is present
+                line["eager_rocm"]["port"] = port
+            except Exception as e:
+                line["eager_rocm"] = {**port, "reference_error": repr(e)}
+            if line["eager_rocm"].get("value"):
+                line["eager_rocm"]["product_over_eager"] = line["value"] / line["eager_rocm"]["value"]
             torch.cuda.empty_cache()
             line["cpu_baseline"] = cpu_baseline(args.cpu_rays)
             par = line["cpu_baseline"].get("parity_on_sample", {})
             for other in others:
                 if isinstance(par, dict) and other in par and key_of[other] in line:
                     line[key_of[other]]["parity_on_sample"] = par[other]
+        if world == 1 and not args.no_extras:
+            try:
+                torch.cuda.empty_cache()
+                line["launcher"] = launcher_eval_leg(dev, model_c, model_f, args.launcher_frames)
+            except Exception as e:                                # an extra must never cost the headline
+                line["launcher"] = {"error": repr(e)}
+            line["config"]["device"]["pattern_store"] = pattern_store_probe()
         line["ranks_seen"] = int(dist.get_world_size()) if dist is not None else 1
-        line["summary"] = summary_of(line)                                # LAST key: the driver keeps only the tail of the line
-        print(json.dumps(line), flush=True)
+        line["summary"] = summary_of(line)
+        emit(line)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
+COMPACT_LIMIT = 6144            # bytes: the driver's record keeps ~8 KB of stdout tail; the final line must fit with room to spare
+ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_algorithmic", "avg_launch_ms", "traffic",
+                 "algorithmic_hbm_bytes_per_launch", "sustained_clock_mhz", "frac_at_sustained_clock")
+CPU_BASELINE_KEYS = ("value", "unit", "kind", "cores", "host_cores", "sample")
+
+
+def _sig(x, digits=6):
+    """Floats to `digits` significant digits (the compact line is a record, not a checkpoint); containers recursively."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def compact_line(line):
+    """The ONE final stdout line (<= COMPACT_LIMIT bytes): the contract's keys, `roofline` and `cpu_baseline` as flat objects,
+    `summary` (flat scalars).  Everything else (per-kernel objects, *_detail, parity_on_sample, tiny, train ...) is in the detail
+    line printed before it and in bench_detail.json."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: line.get(k) for k in head}
+    out["config"] = {"workload": (line.get("config") or {}).get("workload")}
+    out["ranks_seen"] = line.get("ranks_seen")
+    rf = line.get("roofline")
+    if isinstance(rf, dict):
+        out["roofline"] = {k: rf.get(k) for k in ROOFLINE_KEYS if k in rf}
+        if isinstance(rf.get("note_short", rf.get("note")), str):
+            out["roofline"]["note"] = rf.get("note_short", rf["note"])[:120]
+    cb = line.get("cpu_baseline")
+    if isinstance(cb, dict):
+        out["cpu_baseline"] = {k: cb.get(k) for k in CPU_BASELINE_KEYS}
+        if isinstance(out["cpu_baseline"].get("sample"), str):
+            out["cpu_baseline"]["sample"] = out["cpu_baseline"]["sample"][:200]
+    out["detail"] = "bench_detail.json (and the stdout line before this one)"
+    summary = _sig({k: v for k, v in (line.get("summary") or {}).items() if v is not None})
+    out = _sig(out)
+    if len(json.dumps({**out, "summary": summary})) >= COMPACT_LIMIT:      # never lose the record to an overgrown summary: shed it from the back
+        out["summary_truncated"] = True
+        keys = list(summary)
+        while keys and len(json.dumps({**out, "summary": summary})) >= COMPACT_LIMIT:
+            summary.pop(keys.pop())
+    out["summary"] = summary                                                # LAST key
+    return out
+
+
+def emit(line):
+    """Detail first (one stdout line + bench_detail.json), the compact record LAST."""
+    detail = json.dumps({"bench_detail": line})
+    for d in (os.path.join(ROOT, "gpurun_out"), ROOT):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, "bench_detail.json"), "w") as f:
+                    f.write(detail + "\n")
+            except OSError:
+                pass
+    print(detail, flush=True)
+    print(json.dumps(compact_line(line)), flush=True)
+
+
 def summary_of(line):
-    """Flat scalars at the very end of the JSON line (the driver's record keeps a few KB of tail): everything a reader needs to check
-    the claims of DESIGN.md against the driver's own run."""
+    """Flat scalars of the compact line: everything a reader needs to check the claims of DESIGN.md against the driver's own run."""
     def g(*path, default=None):
         o = line
         for k in path:
@@ -1053,11 +1259,8 @@ def summary_of(line):
             o = o[k]
         return o
     s = {"value_rays_s": line.get("value"), "ms_per_step": line.get("ms_per_step"), "n_gpus": line.get("n_gpus"),
-         "ranks_seen": line.get("ranks_seen"), "dtype": line.get("dtype"),
-         "roofline_frac": g("roofline", "frac"), "roofline_frac_algorithmic": g("roofline", "frac_algorithmic"),
-         "roofline_frac_at_sustained_clock": g("roofline", "frac_at_sustained_clock"),
-         "roofline_avg_launch_ms": g("roofline", "avg_launch_ms"), "roofline_traffic_bytes": g("roofline", "traffic"),
-         "sustained_clock_mhz": g("roofline", "sustained_clock_mhz"),
+         "ranks_seen": line.get("ranks_seen"),
+         "roofline_frac": g("roofline", "frac"), "roofline_avg_launch_ms": g("roofline", "avg_launch_ms"),
          "split_f16_rays_s": g("split_f16", "value"), "split_bf16_rays_s": g("split_bf16", "value"),
          "split_f16_fine_launch_ms": g("split_f16", "roofline", "avg_launch_ms"),
          "split_bf16_fine_launch_ms": g("split_bf16", "roofline", "avg_launch_ms"),
@@ -1074,17 +1277,24 @@ def summary_of(line):
             s[f"train_{prec}_{tag}_clock_mhz"] = k.get("sustained_clock_mhz")
             s[f"train_{prec}_{tag}_ms_at_2400mhz"] = k.get("ms_at_nominal_clock")
     ar = g("train", "allreduce") or {}
+    ps = g("config", "device", "pattern_store") or {}
     s.update({"train_allreduce_us": ar.get("allreduce_us"), "train_bytes_allreduced": ar.get("bytes_allreduced"),
               "train_ranks_seen": ar.get("ranks_seen"),
               "hbm_fill_gbs": g("config", "device", "hbm_fill_gbs"), "hbm_copy_gbs": g("config", "device", "hbm_copy_gbs"),
+              "pattern_store_gbs": ps.get("stream_nt_gbs"), "pattern_store_rows_gbs": ps.get("rows_nt_gbs"),
+              "pattern_store_first_touch_gbs": ps.get("first_touch_stream_nt_gbs"), "pattern_store_seq_gbs": ps.get("seq_nt_gbs"),
               "engine_clock_mhz": g("config", "device", "engine_clock_mhz"),
-              "eager_rocm_rays_s": g("eager_rocm", "value"), "product_over_eager": g("eager_rocm", "product_over_eager"),
+              "eager_rocm_rays_s": g("eager_rocm", "value"), "eager_rocm_kind": g("eager_rocm", "kind"),
+              "eager_rocm_port_rays_s": g("eager_rocm", "port", "value"), "product_over_eager": g("eager_rocm", "product_over_eager"),
               "cpu_baseline_rays_s": g("cpu_baseline", "value"), "cpu_baseline_kind": g("cpu_baseline", "kind"),
-              "cpu_baseline_cores": g("cpu_baseline", "cores"), "host_cores": g("cpu_baseline", "host_cores"),
               "abs_dpsnr_db_f32": g("cpu_baseline", "parity_on_sample", "f32", "abs_dpsnr_db_fine"),
               "abs_dpsnr_db_f16x3": g("cpu_baseline", "parity_on_sample", "f16x3", "abs_dpsnr_db_fine"),
               "abs_dpsnr_db_bf16x3": g("cpu_baseline", "parity_on_sample", "bf16x3", "abs_dpsnr_db_fine"),
-              "tiny_rays_s": g("tiny", "value")})
+              "tiny_rays_s": g("tiny", "value"), "tiny_cpu_rays_s": g("tiny", "cpu_baseline", "value"),
+              "tiny_cpu_kind": g("tiny", "cpu_baseline", "kind"),
+              "launcher_eval_frames_s": g("launcher", "launcher_eval_frames_s"),
+              "launcher_gpu_s_per_frame": g("launcher", "launcher_gpu_s_per_frame"),
+              "launcher_wall_over_gpu": g("launcher", "launcher_wall_over_gpu")})
     return s
 
 

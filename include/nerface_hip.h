@@ -27,7 +27,7 @@ typedef void* nf_stream_t; /* hipStream_t */
 #define NF_EINVAL (-22)
 
 /* ---- library ------------------------------------------------------------------------------------ */
-int         nf_abi_version(void);            /* bumped on any signature change                        */
+int         nf_abi_version(void);            /* bumped on any signature / layout change; now 2        */
 const char* nf_error_string(int code);
 const char* nf_build_info(void);             /* "gfx950 <compiler> <date>"                            */
 

@@ -76,15 +76,19 @@ def import_reference_tiny():
         return sys.modules["_ref_tiny_nerf"]
     saved = _expose_reference_nerf()
     root = import_root()
+    mine = sys.modules.pop("tiny_nerf", None)          # the product has a module of the same name (bench.py imports it first)
     sys.path.insert(0, root)
     try:
         import matplotlib
         matplotlib.use("Agg")
         mod = importlib.import_module("tiny_nerf")
+        assert getattr(mod, "__file__", "").startswith(root), (mod.__file__, root)
+        sys.modules["_ref_tiny_nerf"] = sys.modules.pop("tiny_nerf")
     finally:
         sys.path.remove(root)
         _hide_reference_nerf(saved)
-    sys.modules["_ref_tiny_nerf"] = sys.modules.pop("tiny_nerf")
+        if mine is not None:
+            sys.modules["tiny_nerf"] = mine
     return mod
 
 

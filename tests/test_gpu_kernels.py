@@ -268,6 +268,35 @@ def test_resample_merge_fast_path_is_bit_identical(hip_lib, gpu):
     bins, w, u = (torch.from_numpy(gd[k]) for k in ("bins", "w", "u"))
     z_c = torch.cat((bins[:, :1], bins), dim=-1)                               # 64 depths whose interior midpoints are not the bins, fine
     check(z_c.contiguous(), torch.cat((w[:, :1], w, w[:, :1]), dim=-1).contiguous(), 128, u)
+    # NaN samples (NaN u / NaN weights: a diverged model) stay NaN in z_fine: the register sort is a v_min network, which would
+    # swallow them and duplicate a neighbour -- such rows take the compare-swap path, whose comparison is a total order with NaNs last
+    # (ADVICE r04): z_fine equals torch.sort(cat(depths, samples)), NaNs included.
+    for nc, nf in ((64, 128), (64, 64), (33, 100)):
+        z_c = torch.sort(torch.rand((70, nc), generator=g) * 0.6 + 0.2, dim=-1)[0]
+        w_c = torch.rand((70, nc), generator=g)
+        u = torch.rand((70, nf), generator=g)
+        u[5, 7] = float("nan")
+        u[6, ::3] = float("nan")
+        w_c[9, nc // 3] = float("nan")
+        z_f, z_s = ops.resample_merge(z_c.to(gpu), w_c.to(gpu), nf, u.to(gpu), want_samples=True)
+        want_s = ops.sample_pdf((0.5 * (z_c[:, 1:] + z_c[:, :-1])).to(gpu), w_c[:, 1:-1].contiguous().to(gpu), nf, u.to(gpu))
+        assert torch.equal(torch.isnan(z_s), torch.isnan(want_s)) and torch.equal(torch.nan_to_num(z_s, nan=-1.0), torch.nan_to_num(want_s, nan=-1.0))
+        assert int(torch.isnan(z_s[5]).sum()) == 1 and int(torch.isnan(z_s[6]).sum()) == len(range(0, nf, 3)) and bool(torch.isnan(z_s[9]).any())
+        cat = torch.cat((z_c.to(gpu), z_s), dim=-1)
+        want_f = torch.sort(cat.cpu(), dim=-1)[0]                             # torch's order: ascending, NaNs last
+        for got in (z_f, ops.sort_rows(cat.contiguous())):                    # the fused kernel and the stand-alone row sort
+            assert torch.equal(torch.isnan(got).cpu(), torch.isnan(want_f))
+            assert torch.equal(torch.nan_to_num(got, nan=-1.0).cpu(), torch.nan_to_num(want_f, nan=-1.0))
+    # ... and through the general kernel (sizes beyond the register path) with +inf among the values: inf sorts before the NaNs
+    z_c = torch.sort(torch.rand((6, 140), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    w_c = torch.rand((6, 140), generator=g)
+    u = torch.rand((6, 100), generator=g)
+    u[2, 5] = float("nan")
+    z_c[3, -1] = float("inf")
+    z_f, z_s = ops.resample_merge(z_c.to(gpu), w_c.to(gpu), 100, u.to(gpu), want_samples=True)
+    want_f = torch.sort(torch.cat((z_c, z_s.cpu()), -1), -1)[0]
+    assert torch.equal(torch.isnan(z_f).cpu(), torch.isnan(want_f)) and torch.equal(torch.nan_to_num(z_f, nan=-1.0).cpu(), torch.nan_to_num(want_f, nan=-1.0))
+    assert int(torch.isnan(z_f[2]).sum()) == 1 and bool(torch.isinf(z_f[3]).any())
 
 
 def test_resample_merge(hip_lib, gpu):

@@ -149,9 +149,10 @@ def test_bench_two_ranks_one_gpu_gloo(hip_lib, gpu):
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--train-steps", "3"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    from tests.util import parse_bench_stdout
+    c, d = parse_bench_stdout(r.stdout.decode())
+    assert c["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["steps"] == 1 and abs(c["value"] - d["value"]) < 1e-5 * d["value"]
+    assert c["summary"]["train_bytes_allreduced"] == 4 * (2 * 552196 + 1000 * 32)
     assert d["n_gpus"] == 2 and d["steps"] == 1 and d["scaling"] == "weak" and d["dtype"] == "f32" and d["value"] > 0
     assert abs(d["value"] * d["ms_per_step"] * 1e-3 - 2 * 512 * 512) < 1.0                    # two ranks x one frame each
     assert "split_f16" in d and "split_bf16" in d and "cpu_baseline" not in d
@@ -163,6 +164,26 @@ def test_bench_two_ranks_one_gpu_gloo(hip_lib, gpu):
     assert d["summary"]["train_bytes_allreduced"] == ar["bytes_allreduced"] and d["summary"]["ranks_seen"] == 2
     assert "data parallel over 2 GPUs" in d["train"]["workload"]
     assert d["roofline"]["traffic"] is None                                                     # PMC passes are an N = 1 extra
+
+
+def test_bench_bare_gpus_2_launches_its_own_ranks(hip_lib, gpu):
+    """A bare `python bench.py --gpus 2` (no launcher, WORLD_SIZE unset) starts the two ranks itself and reports them: n_gpus == 2,
+    ranks_seen == 2 on the compact line (it used to measure one GPU and say so nowhere).  Two ranks on this one
+    GPU with NERFACE_DIST_BACKEND=gloo.  A launcher whose world size disagrees with --gpus is refused."""
+    import subprocess
+    from tests.util import parse_bench_stdout
+    env = dict(os.environ, NERFACE_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--no-extras"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    c, d = parse_bench_stdout(r.stdout.decode())
+    assert c["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["summary"]["ranks_seen"] == 2
+    assert abs(c["value"] * c["ms_per_step"] * 1e-3 - 2 * 512 * 512) < 30.0                    # two ranks x one frame each (6 significant digits)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"],
+                       env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0 and b"must agree" in r.stderr
 
 
 def _torchrun(n, port):
@@ -200,9 +221,9 @@ def test_rccl_single_rank_runs_every_collective(hip_lib, gpu, tmp_path):
     r = subprocess.run(_torchrun(1, port + 1) + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--mode", "train", "--steps", "3", "--warmup", "1"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
-    assert len(lines) == 1, lines
-    d = json.loads(lines[0])
+    from tests.util import parse_bench_stdout
+    c, d = parse_bench_stdout(r.stdout.decode())
+    assert c["n_gpus"] == 1 and c["ranks_seen"] == 1 and c["roofline"]["bound"] == "mfma"
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and d["roofline"]["bound"] == "mfma" and len(d["roofline"]["kernels"]) == 3
     # RCCL really ran the flat all-reduce on device memory: the line says how many ranks the communicator saw, what moved, how long it took
     assert d["ranks_seen"] == 1 and d["allreduce"]["backend"] == "nccl" and d["allreduce"]["calls"] == 4
@@ -249,12 +270,15 @@ def test_eight_ranks_one_gpu_gloo(hip_lib, gpu, tmp_path):
     r = subprocess.run(_torchrun(8, port + 2) + [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "1", "--warmup", "0", "--no-extras"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    from tests.util import parse_bench_stdout
+    c, d = parse_bench_stdout(r.stdout.decode())
+    assert c["n_gpus"] == 8 and c["ranks_seen"] == 8
     assert d["n_gpus"] == 8 and abs(d["value"] * d["ms_per_step"] * 1e-3 - 8 * 512 * 512) < 1.0
     r = subprocess.run(_torchrun(8, port + 3) + [os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mode", "train", "--steps", "2", "--warmup", "1"],
                        env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
     assert r.returncode == 0, r.stderr.decode()[-3000:]
-    d = json.loads([l for l in r.stdout.decode().splitlines() if l.startswith("{")][0])
+    c, d = parse_bench_stdout(r.stdout.decode())
+    assert c["n_gpus"] == 8 and c["ranks_seen"] == 8 and c["summary"]["ranks_seen"] == 8
     assert d["n_gpus"] == 8 and d["config"]["rays_per_step"] == 8 * 2048 and d["value"] > 0
     assert d["ranks_seen"] == 8 and d["allreduce"]["calls"] == 3 and d["bytes_allreduced"] == 4 * (2 * 552196 + 1000 * 32) and d["allreduce_us"] > 0
 

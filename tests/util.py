@@ -99,3 +99,17 @@ def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=
         for name in list(stages):
             stages[name] = torch.cat(stages[name], dim=0)
     return tuple(torch.cat(t, dim=0) for t in zip(*parts))
+
+
+def parse_bench_stdout(text):
+    """bench.py prints two JSON lines: the detail object ({"bench_detail": {...}}) and, LAST, the compact record the driver parses.
+    Returns (compact, detail)."""
+    import json
+    lines = [l for l in text.splitlines() if l.startswith("{")]
+    assert len(lines) == 2, [l[:80] for l in lines]
+    detail = json.loads(lines[0])
+    assert list(detail) == ["bench_detail"]
+    compact = json.loads(lines[1])
+    assert len(lines[1]) < 6144 and "bench_detail" not in compact
+    return compact, detail["bench_detail"]
+
