@@ -15,6 +15,20 @@
 
 static inline hipStream_t nf_s(nf_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Compute units of the CURRENT device (cached per device index: a process may drive several GPUs).  Persistent grids and the
+// weight-gradient slice plan are sized from it; without a device (host-only size queries in the CPU tests) it is gfx950's 256.
+static inline int64_t nf_cu_count() {
+    static int n[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+    if (!n[dev]) {
+        int v = 0;
+        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        n[dev] = v;
+    }
+    return n[dev];
+}
+
 
 // IEEE single ops that must not be contracted into FMAs (bit parity with the reference's
 // separate mul / add tensor ops).  The library is also built with -ffp-contract=off.

@@ -495,19 +495,6 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
     }
 }
 
-// compute units of the CURRENT device (cached per device index: a process may drive several GPUs)
-static int64_t nf_cu_count() {
-    static int n[64] = {0};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
-    if (!n[dev]) {
-        int v = 0;
-        if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        n[dev] = v;
-    }
-    return n[dev];
-}
-
 static int nf_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)

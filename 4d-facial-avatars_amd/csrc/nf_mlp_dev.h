@@ -64,9 +64,6 @@ struct NfNoSide {
 // plus a v_add_co / v_addc pair per four loads in the global form.  In a one-wave-per-SIMD MFMA loop that vector arithmetic and the
 // wider VMEM issue are not free: the f32 inference kernel went from 91.6 to 86.7 ms per fine launch on this change alone
 // (profiles/r03_mlp_f32_stream.md).
-#ifndef NF_TRAIN_WBUF
-#define NF_TRAIN_WBUF 1
-#endif
 typedef unsigned nf_u32x4_ __attribute__((ext_vector_type(4)));
 template <int NO>
 __device__ __forceinline__ void nf_load_w_buf(f32x4 (&w)[NO], __amdgpu_buffer_rsrc_t rsrc, int chunk, int lane) {
@@ -80,12 +77,8 @@ __device__ __forceinline__ void nf_mma_from_lds_side(f32x4 (&acc)[NT][16], const
                                                      int lane, Side& side) {
     const int g = lane >> 4, c = lane & 15;
     f32x4 wa[NO], wb[NO], b0[NT], b1[NT];
-#if NF_TRAIN_WBUF
     const __amdgpu_buffer_rsrc_t wr = __builtin_amdgcn_make_buffer_rsrc(const_cast<f32x4*>(wsec), (short)0, nch * (NO * 1024), 0x00020000);
 #define NF_LOADW_(dst, chunk) nf_load_w_buf<NO>(dst, wr, chunk, lane)
-#else
-#define NF_LOADW_(dst, chunk) nf_load_w<NT, NO>(dst, wsec + (size_t)(chunk) * NO * 64, lane)
-#endif
     NF_LOADW_(wa, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t) b0[t] = act4[nf_act_idx4(16 * t + c, g)];
@@ -290,10 +283,7 @@ __device__ __forceinline__ void nf_copy_write(const f32x4 v, const NfSlabCopy& c
     // aux 2 = nt (non-temporal): the 9 KB per point stream to HBM and are not read back before the weight-gradient kernel; as ordinary
     // write-back stores they pushed the 2 MB weight image out of L2 and delayed the in-order vmcnt of the weight loads behind them
     // (forward 2.224 -> 2.184 ms, chain 1.972 -> 1.940 ms per 262144-point launch, profiles/r03_experiments.md)
-#ifndef NF_COPY_AUX
-#define NF_COPY_AUX 2
-#endif
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, NF_COPY_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(nf_u32x4, v), cp.rsrc, (int)(cp.row0_b + (unsigned)(p * W4 + q) * 16u), 0, 2);
 }
 template <int W4>
 __device__ __forceinline__ void nf_copy_rows(const f32x4* act4, const NfSlabCopy& cp, int inst, int lane) {

@@ -166,7 +166,8 @@ struct NfDwGroupSet {                                         // passed by value
 // cost, and the grid holds exactly the (group, slice) pairs that exist, at most n_cu of them: workgroups are dealt to the eight XCDs
 // round-robin, so a 2-D grid padded with empty blocks put 33 live workgroups on some XCDs' 32 CUs and doubled the kernel time.
 // Returns the largest slice count (= number of slabs the reduction sums).
-static inline int nf_dw_plan_groups(NfDwGroup* g, int n_groups, int64_t n_points, int* first_block = nullptr, int n_cu = 256) {
+static inline int nf_dw_plan_groups(NfDwGroup* g, int n_groups, int64_t n_points, int* first_block = nullptr, int n_cu = 0) {
+    if (n_cu <= 0) n_cu = (int)nf_cu_count();                       // the device the caller is about to launch on
     int shares = 0;
     for (int i = 0; i < n_groups; ++i) shares += g[i].share;
     int unit = (2 * n_cu) / shares;                                  // slices of a share-2 group
