@@ -719,9 +719,90 @@ def device_info(dev):
         torch.cuda.empty_cache()
     except Exception as e:
         probe = {"hbm_probe_error": repr(e)}
+    probe["env"] = {k: v for k, v in os.environ.items() if re.match(r"(HSA|HIP|ROCR|ROCM|GPU|AMD|PYTORCH|NCCL|RCCL)_", k)}   # what differs box to box
     return {**probe, "name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": cus, "engine_clock_mhz": mhz,
             "hbm_gib": round(p.total_memory / 2 ** 30, 1),
             "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
+
+
+def _gpu_sysfs(dev):
+    """sysfs directory of the amdgpu device `dev` runs on (None if the container does not show it)."""
+    import glob
+    cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "power_dpm_force_performance_level")))
+    if not cards:
+        return None
+    try:                                                             # match by PCI bus id when torch reports it
+        want = torch.cuda.get_device_properties(dev).pci_bus_id
+        for d in cards:
+            if int(os.path.basename(os.path.realpath(d)).split(":")[1], 16) == want:
+                return d
+    except Exception:
+        pass
+    return cards[min(dev.index or 0, len(cards) - 1)]
+
+
+def power_probe(dev, legs, seconds=1.5, period=0.02):
+    """What the board's power management does to each inference kernel on THIS box: socket power, engine / fabric / memory clock read
+    from amdgpu's sysfs nodes every 20 ms while the kernel runs back to back for `seconds`, beside the board's power cap and performance
+    level.  Boxes of the pool differ in how they hold the cap: the builder's lower the engine clock under the 16-bit MFMA kernels
+    (2.1-2.2 GHz), the driver's boxes of rounds 3 and 4 reported 2.38 GHz for every kernel and 1.35x (inference) to 2.9x (training
+    forward) the busy cycles.  Outside every timed region; reads only."""
+    import glob, threading
+    d = _gpu_sysfs(dev)
+    if d is None:
+        return {"error": "no amdgpu sysfs node visible"}
+    hw = (glob.glob(os.path.join(d, "hwmon", "hwmon*")) or [None])[0]
+
+    def rd(path, num=True):
+        try:
+            t = open(path).read().strip()
+            return float(t) if num else t
+        except Exception:
+            return None
+    pwr = next((f for f in ("power1_average", "power1_input") if hw and os.path.exists(os.path.join(hw, f))), None)
+    static = {"sysfs": d, "perf_level": rd(os.path.join(d, "power_dpm_force_performance_level"), False),
+              "power_cap_w": (rd(os.path.join(hw, "power1_cap")) or 0) / 1e6 if hw else None,
+              "power_cap_max_w": (rd(os.path.join(hw, "power1_cap_max")) or 0) / 1e6 if hw else None,
+              "power_node": pwr}
+    for node in ("pp_dpm_sclk", "pp_dpm_fclk", "pp_dpm_mclk", "current_compute_partition", "current_memory_partition"):
+        static[node] = rd(os.path.join(d, node), False)
+
+    def star(node):                                                  # the level amdgpu marks as current in a pp_dpm_* table (MHz)
+        t = rd(os.path.join(d, node), False) or ""
+        m = re.search(r"(\d+)\s*Mhz\s*\*", t, re.I)
+        return float(m.group(1)) if m else None
+    out = {"static": static}
+    for name, fn in legs:
+        fn()
+        torch.cuda.synchronize()
+        rows, stop = [], threading.Event()
+
+        def sample():
+            while not stop.is_set():
+                rows.append((rd(os.path.join(hw, pwr)) if pwr else None, rd(os.path.join(hw, "freq1_input")) if hw else None,
+                             star("pp_dpm_sclk"), star("pp_dpm_fclk"), star("pp_dpm_mclk")))
+                time.sleep(period)
+        th = threading.Thread(target=sample, daemon=True)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n, t0 = 0, time.perf_counter()
+        th.start()
+        e0.record()
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            n += 1
+            if n % 4 == 0:
+                torch.cuda.synchronize()                             # keep the queue short: the loop ends on time
+        e1.record()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join()
+        rows = rows[len(rows) // 4:]                                  # the first quarter is the ramp
+        mean = lambda k, sc: (sum(r[k] for r in rows if r[k] is not None) / max(1, sum(r[k] is not None for r in rows)) * sc
+                              if any(r[k] is not None for r in rows) else None)
+        out[name] = {"launch_ms": e0.elapsed_time(e1) / n, "launches": n, "samples": len(rows), "power_w": mean(0, 1e-6),
+                     "power_w_max": max((r[0] for r in rows if r[0] is not None), default=0) * 1e-6 if pwr else None,
+                     "sclk_mhz_hwmon": mean(1, 1e-6), "sclk_mhz_dpm": mean(2, 1.0), "fclk_mhz_dpm": mean(3, 1.0), "mclk_mhz_dpm": mean(4, 1.0)}
+    return out
 
 
 def _pmc_guard():
@@ -1180,6 +1261,12 @@ def main():
             except Exception as e:                                # an extra must never cost the headline
                 line["launcher"] = {"error": repr(e)}
             line["config"]["device"]["pattern_store"] = pattern_store_probe()
+            try:
+                line["config"]["device"]["power"] = power_probe(dev, (("f32", lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
+                                                                      ("f16x3", lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z)),
+                                                                      ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z))))
+            except Exception as e:
+                line["config"]["device"]["power"] = {"error": repr(e)}
         line["ranks_seen"] = int(dist.get_world_size()) if dist is not None else 1
         line["summary"] = summary_of(line)
         emit(line)
@@ -1283,6 +1370,7 @@ def summary_of(line):
               "hbm_fill_gbs": g("config", "device", "hbm_fill_gbs"), "hbm_copy_gbs": g("config", "device", "hbm_copy_gbs"),
               "pattern_store_gbs": ps.get("stream_nt_gbs"), "pattern_store_rows_gbs": ps.get("rows_nt_gbs"),
               "pattern_store_first_touch_gbs": ps.get("first_touch_stream_nt_gbs"), "pattern_store_seq_gbs": ps.get("seq_nt_gbs"),
+              "pattern_store_default_policy_gbs": ps.get("stream_gbs"), "pattern_store_rows_default_policy_gbs": ps.get("rows_gbs"),
               "engine_clock_mhz": g("config", "device", "engine_clock_mhz"),
               "eager_rocm_rays_s": g("eager_rocm", "value"), "eager_rocm_kind": g("eager_rocm", "kind"),
               "eager_rocm_port_rays_s": g("eager_rocm", "port", "value"), "product_over_eager": g("eager_rocm", "product_over_eager"),
@@ -1295,6 +1383,13 @@ def summary_of(line):
               "launcher_eval_frames_s": g("launcher", "launcher_eval_frames_s"),
               "launcher_gpu_s_per_frame": g("launcher", "launcher_gpu_s_per_frame"),
               "launcher_wall_over_gpu": g("launcher", "launcher_wall_over_gpu")})
+    pw = g("config", "device", "power") or {}
+    st = pw.get("static") or {}
+    s.update({"power_cap_w": st.get("power_cap_w"), "perf_level": st.get("perf_level")})
+    for prec in ("f32", "f16x3", "bf16x3"):                          # how THIS box holds its power cap under each inference kernel
+        o = pw.get(prec) or {}
+        s.update({f"power_w_{prec}": o.get("power_w"), f"sclk_mhz_{prec}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm"),
+                  f"fclk_mhz_{prec}": o.get("fclk_mhz_dpm")})
     return s
 
 

@@ -68,6 +68,77 @@ def run_reference(ref, c, grad=False):
     return out, grads
 
 
+NOFLIP = "soft_train_noflip_64_64"
+
+
+def _fp64_autograd(c):
+    """The oracle in float64 with autograd on case `c`: (param grads coarse, fine, latent grad, smallest |ReLU input|)."""
+    pc = {k: v.double().clone().requires_grad_(True) for k, v in c["p_coarse"].items()}
+    pf = {k: v.double().clone().requires_grad_(True) for k, v in c["p_fine"].items()}
+    lat = c["latent"].double().clone().requires_grad_(True)
+    d = lambda t: None if t is None else t.double()
+    keep, rec = torch.relu, []
+
+    def relu(v):                                   # MLP units as they are; the density ReLU (V:52) in units of the x40 head
+        rec.append(float(v.detach().abs().min()) / (1.0 if v.shape[-1] in (256, 128) else 40.0))
+        return keep(v)
+    torch.relu = relu
+    try:
+        o = O.render_rays(pc, pf, d(c["ro"]), d(c["rd"]), d(c["expr"]), lat, d(c["bg"]), O.NEAR, O.FAR, c["n_coarse"], c["n_fine"],
+                          t_rand=d(c["t_rand"]), noise_c=d(c["noise_c"]), u=d(c["u"]), noise_f=d(c["noise_f"]))
+    finally:
+        torch.relu = keep
+    O.train_loss(o[0], o[3], d(c["tgt"]), lat).backward()
+    return pc, pf, lat.grad, min(rec)
+
+
+def _worst_vs_fp64(g, pc, pf):
+    rel = lambda a, b: float((a.double() - b).norm() / (b.norm() + 1e-30))
+    return max(rel(g[f"{tag}.{k}"], v.grad) for tag, po in (("coarse", pc), ("fine", pf)) for k, v in po.items()
+               if g[f"{tag}.{k}"] is not None)
+
+
+def search_soft_grads(ref, n_frames=2000, keep=8):
+    """How oracle/cases.py's NOFLIP frame was chosen.  A ReLU unit whose input lies within rounding of zero takes different sides in two
+    fp32 evaluations and moves a gradient tensor by ~1e-3 -- that says nothing about the backward arithmetic.  Rank the frames by their
+    smallest |ReLU input| (fp64 oracle, both networks + the density ReLU), then keep those on which the reference's fp32 autograd and the
+    oracle's fp64 autograd agree to rounding in EVERY tensor: an fp64 pipeline perturbs every depth and activation at the fp32 rounding
+    level, the same size of perturbation another fp32 implementation is allowed, so such a frame has no decision within reach."""
+    ranked = []
+    for f in range(n_frames):
+        C.CASES["_probe"] = dict(C.CASES[NOFLIP], frame=f)
+        ranked.append((_fp64_autograd(C.build_case("_probe"))[3], f))
+    ranked.sort(reverse=True)
+    for margin, f in ranked[:keep]:
+        C.CASES["_probe"] = dict(C.CASES[NOFLIP], frame=f)
+        c = C.build_case("_probe")
+        _, g = run_reference(ref, c, grad=True)
+        pc, pf, _, _ = _fp64_autograd(c)
+        print(f"frame {f}: smallest |ReLU input| {margin:.2e}, reference fp32 vs oracle fp64 autograd: worst tensor {_worst_vs_fp64(g, pc, pf):.2e}")
+    C.CASES.pop("_probe")
+
+
+def make_soft_grads(ref):
+    """soft_train_noflip_64_64_grads.npz: the reference's autograd (Q9 shim) on the soft-family training case, FULL gradient tensors
+    of both models and the latent row (rel-L2 <= 1e-4 per tensor, end to end)."""
+    c = C.build_case(NOFLIP)
+    out, g = run_reference(ref, c, grad=True)
+    pc, pf, lat64, margin = _fp64_autograd(c)
+    worst = _worst_vs_fp64(g, pc, pf)
+    print(f"[{NOFLIP}] loss {float(g['loss']):.6f}; smallest |ReLU input| {margin:.2e}; reference fp32 vs oracle fp64 autograd: worst tensor "
+          f"{worst:.2e}, latent {float((g['latent'].double() - lat64).norm() / lat64.norm()):.2e}")
+    assert worst < 1e-5, "this frame has a ReLU decision within fp32 rounding: pick another (search_soft_grads)"
+    blob = {"loss": g["loss"].numpy(), "latent": g["latent"].numpy(), "relu_margin_fp64": np.float64(margin),
+            "params_checksum": np.float64(C.params_checksum(c["p_coarse"]) + C.params_checksum(c["p_fine"]))}
+    for n, a in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"], out):
+        blob[n] = a.detach().numpy()
+    for k, v in g.items():
+        if k in ("loss", "latent"):
+            continue
+        blob[("none:" if v is None else "full:") + k] = np.zeros(0, np.float32) if v is None else v.numpy()
+    np.savez_compressed(os.path.join(OUT, f"{NOFLIP}_grads.npz"), **blob)
+
+
 def lcode_ref_model(ref, params):
     m = ref.models.ConditionalBlendshapeLearnableCodeNeRFModel(
         num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True,
@@ -253,6 +324,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "lcode_grads":        # regenerate only this fixture
         make_lcode_grads(ref)
         return
+    if len(sys.argv) > 1 and sys.argv[1] == "soft_grads":         # `soft_grads search`: how the frame of the case was chosen
+        search_soft_grads(ref) if sys.argv[2:] == ["search"] else make_soft_grads(ref)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "pe_pdf":
         make_pe_pdf(ref)
         return
@@ -271,6 +345,8 @@ def main():
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None     # `cases NAME...`: only these 7-tuple fixtures
     for name in (only or C.CASES):
+        if name == NOFLIP:                                            # gradient fixture only (make_soft_grads)
+            continue
         c = C.build_case(name)
         out_ref, _ = run_reference(ref, c)
         st = {}
@@ -331,6 +407,7 @@ def main():
     print("lcode exact:", all(torch.equal(a, b) for a, b in zip(out_ref, out_or)), "w_last range", float(out_ref[6].min()), float(out_ref[6].max()))
     np.savez_compressed(os.path.join(OUT, "lcode_eval_det_64_128.npz"), **{n: a.numpy() for n, a in zip(names7, out_ref)})
     make_lcode_grads(ref)
+    make_soft_grads(ref)
 
     # gradient fixture (reference autograd with the Q9 shim)
     c = C.build_case("train_rand_64_64")

@@ -107,6 +107,36 @@ def test_gradient_fixture():
             assert abs(float(v.grad.double().norm()) - want) <= 1e-4 * want + 1e-9, (tag, k)
 
 
+def test_soft_noflip_gradient_fixture_full_tensors():
+    """SURVEY §8(d)(iii) end to end, checker side: the oracle's fp32 AND fp64 autograd against the reference's autograd with FULL gradient
+    tensors (tests/golden/soft_train_noflip_64_64_grads.npz: soft density head, a frame without a ReLU decision within rounding of zero --
+    oracle/make_golden.py `soft_grads`): rel-L2 <= 1e-4 per tensor (measured 2e-6), the gate the `-m gpu` twin holds the product to."""
+    c = C.build_case("soft_train_noflip_64_64")
+    g = np.load(os.path.join(GOLD, "soft_train_noflip_64_64_grads.npz"))
+    assert abs(float(g["params_checksum"]) - (C.params_checksum(c["p_coarse"]) + C.params_checksum(c["p_fine"]))) < 1e-6
+    for dt in (torch.float32, torch.float64):
+        f = lambda t: None if t is None else t.to(dt)
+        pc = {k: f(v).clone().requires_grad_(True) for k, v in c["p_coarse"].items()}
+        pf = {k: f(v).clone().requires_grad_(True) for k, v in c["p_fine"].items()}
+        lat = f(c["latent"]).clone().requires_grad_(True)
+        out = O.render_rays(pc, pf, f(c["ro"]), f(c["rd"]), f(c["expr"]), lat, f(c["bg"]), O.NEAR, O.FAR, 64, 64, t_rand=f(c["t_rand"]),
+                            noise_c=f(c["noise_c"]), u=f(c["u"]), noise_f=f(c["noise_f"]))
+        loss = O.train_loss(out[0], out[3], f(c["tgt"]), lat)
+        loss.backward()
+        assert abs(float(loss) - float(g["loss"])) < 1e-6
+        rel = lambda a, b: float(np.linalg.norm(a.double().numpy() - b.astype(np.float64)) / np.linalg.norm(b.astype(np.float64)))
+        assert rel(lat.grad, g["latent"]) < 1e-4
+        n_full = 0
+        for tag, p in (("coarse", pc), ("fine", pf)):
+            for k, v in p.items():
+                if f"none:{tag}.{k}" in g.files:
+                    assert v.grad is None or float(v.grad.abs().max()) == 0.0
+                    continue
+                assert rel(v.grad, g[f"full:{tag}.{k}"]) < 1e-4, (dt, tag, k)
+                n_full += 1
+        assert n_full == 2 * 24
+
+
 def test_lcode_gradient_fixture():
     """Second model family: oracle autograd (fp32) vs the reference's autograd on the training case."""
     c = C.build_case("train_rand_64_64")
