@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/nerface_hip.h"
+#include "nf_sincos.h"
 
 #define NF_WAVE 64
 

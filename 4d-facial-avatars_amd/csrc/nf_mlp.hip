@@ -11,7 +11,7 @@
 //     the next layer's B fragments -- one ds_read_b128 per 64 MFMAs;
 //   * weights stream from L2 (2.2 MB image, shared by every workgroup) as perfectly coalesced 1-KiB
 //     wave loads, one K-chunk ahead of the MFMAs that consume them (register double buffer);
-//   * the 63-wide positional encoding lives in registers in B-fragment order (one sincosf per two
+//   * the 63-wide positional encoding lives in registers in B-fragment order (one sin / cos pair per two
 //     slots) and is consumed twice (layers_xyz.0 and the skip input of layers_xyz.3);
 //   * the per-call constant input columns (expression, latent code, PE(near), PE(far)) never enter
 //     the GEMMs: nf_paper_condition folds them into bias vectors (the `cond` table).
@@ -200,9 +200,14 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c = lane & 15;
     f32x4* act4 = lds + wave * (16 * NT * 64);
+    typedef __attribute__((address_space(1))) f32x4 nf_gf32x4;
+    nf_gf32x4* raw_v = (nf_gf32x4*)raw;               // the output pointer and the grid stride live in VGPRs (see the epilogue)
+    asm volatile("" : "+v"(raw_v));
+    int stride_v = (int)gridDim.x;
+    asm volatile("" : "+v"(stride_v));
     // persistent form: one workgroup per CU walks the point blocks with the grid's stride (no workgroup dispatch between blocks)
 #pragma unroll 1
-    for (int64_t blk = blockIdx.x;; blk += gridDim.x) {
+    for (int64_t blk = blockIdx.x;; blk += __builtin_amdgcn_readfirstlane(stride_v)) {
     const int64_t p0 = (blk * NF_MLP_WAVES + wave) * (16 * NT);
     if (p0 >= n_points) break;                        // wave-uniform; no barriers anywhere below
     int opaque0 = 0;                                  // per-block opaque zero: the weight / bias loads must stay where the layers issue them
@@ -225,7 +230,7 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         const float pz = nf_add(ro[ray * 3 + 2], nf_mul(dz, zz));
         nf_encode_point(px, py, pz, g, pe[t]);
         float s, cs;
-        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
+        nf_sincos(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
     }
 
@@ -310,12 +315,17 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
     nf_pending_b<NT, true>(bj, st);
     nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
-    if (g == 0) {
+    // (the store predicate, the output pointer and the grid stride are re-derived from opaque VGPR copies: as loop invariants of the
+    // persistent block loop they were the last scalar values the allocator could not keep -- 106 SGPRs are in use -- and went through
+    // v_writelane / v_readlane)
+    int lane_o = lane;
+    asm volatile("" : "+v"(lane_o));
+    if ((lane_o >> 4) == 0) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const int64_t p = p0 + 16 * t + c;
             if (p < n_points)
-                reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+                raw_v[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
         }
     }
     }
@@ -357,7 +367,7 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
         const float pz = nf_add(ro[ray * 3 + 2], nf_mul(dz, zz));
         nf_encode_point(px, py, pz, g, pe[t]);
         float s, cs;
-        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
+        nf_sincos(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);   // Quirk Q1: "direction" = (rd_z, near, far)
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
         // dir slots: 64 B per point, the 16 points of a tile are one contiguous KiB
         if (p0 + 16 * t + c < n_points) *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];

@@ -194,18 +194,24 @@ __device__ __forceinline__ void nf_relu_inplace(f32x4 (&acc)[NT][16]) {
         }
 }
 
-// Positional encoding of one point in B-fragment order (see nfl::pe_slot_pair).
+// Positional encoding of one point in B-fragment order (see nfl::pe_slot_pair).  The pair index of slot (j, h) is base(g) + 2 j + h with
+// base = 8 g (24 for g = 3), its component (base + 2 j + h) % 3: the lane-dependent part is only base % 3 = {0, 2, 1, 0}[g], so the
+// coordinates are rotated by that ONCE per point (two lane-invariant masks) and every slot picks by a compile-time index.  (Selecting
+// px / py / pz per slot made 32 loop-invariant lane masks, which the persistent inference kernel kept alive across its block loop:
+// 38 spilled SGPRs, 72 v_readlane per block.)
 __device__ __forceinline__ void nf_encode_point(float px, float py, float pz, int g, f32x4 (&pe)[4]) {
+    const int rot = g == 1 ? 2 : (g == 2 ? 1 : 0);
+    const float q[3] = {rot == 0 ? px : (rot == 1 ? py : pz), rot == 0 ? py : (rot == 1 ? pz : px), rot == 0 ? pz : (rot == 1 ? px : py)};
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         float v[4];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int pidx = (g < 3 ? g * 8 : 24) + j * 2 + h;
-            const int freq = pidx / 3, comp = pidx - 3 * freq;
-            const float x = comp == 0 ? px : (comp == 1 ? py : pz);
+            const int freq = pidx / 3;
+            const float x = q[(j * 2 + h) % 3];                    // component (rot + 2 j + h) % 3
             float s, cs;
-            sincosf(nf_mul(x, (float)(1 << freq)), &s, &cs);
+            nf_sincos(nf_mul(x, (float)(1 << freq)), &s, &cs);
             v[2 * h] = s;
             v[2 * h + 1] = cs;
         }

@@ -489,7 +489,11 @@ __global__ void __launch_bounds__(256) k_grad_reduce(const float* __restrict__ s
 #pragma unroll
             for (int q = 0; q < 4; ++q) a[q] += src[(int64_t)(k + q) * n4];
         }
-        for (; k < ns; ++k) a[k & 3] += src[(int64_t)k * n4];
+        // tail (k is a multiple of 4 here): slabs k, k + 1, k + 2 go to a[0], a[1], a[2] -- the order a[k & 3] gave, without indexing the
+        // accumulator array by a run-time value (the compiler turned that into exec-mask sequences: 29 spilled SGPRs)
+#pragma unroll
+        for (int q = 0; q < 3; ++q)
+            if (k + q < ns) a[q] += src[(int64_t)(k + q) * n4];
         reinterpret_cast<f32x4*>(sum)[e] = (a[0] + a[1]) + (a[2] + a[3]);
     }
 }

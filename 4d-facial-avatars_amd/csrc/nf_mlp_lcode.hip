@@ -132,7 +132,7 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         const float pz = nf_add(ro[ray * 3 + 2], nf_mul(rd[ray * 3 + 2], zz));
         nf_encode_point(px, py, pz, g, pe[t]);
         float s, cs;
-        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
+        nf_sincos(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
     }
     f32x4 acc[NT][16];
@@ -226,7 +226,7 @@ k_lcode_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
         const float pz = nf_add(ro[ray * 3 + 2], nf_mul(rd[ray * 3 + 2], zz));
         nf_encode_point(px, py, pz, g, pe[t]);
         float s, cs;
-        sincosf(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
+        nf_sincos(nf_mul(rd_view[ray * 3 + 2], (float)(1 << g)), &s, &cs);
         dirf[t][0] = (f32x4){s, cs, 0.0f, 0.0f};
         if (p0 + 16 * t + c < n_points) *reinterpret_cast<f32x4*>(saved + S_DIRF * n_points + p * 16 + 4 * g) = dirf[t][0];
 #pragma unroll

@@ -195,7 +195,10 @@ def test_bench_compact_line_fits_the_driver_record():
     line = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line.json")))
     line["launcher"] = {"launcher_eval_frames_s": 2.1234567890123457, "launcher_gpu_s_per_frame": 0.46123456789012345, "launcher_wall_over_gpu": 1.0123456789012345}
     line["config"]["device"]["pattern_store"] = {"stream_nt_gbs": 4321.123456789012, "rows_nt_gbs": 4321.123456789012, "seq_nt_gbs": 4321.123456789012,
-                                                  "first_touch_stream_nt_gbs": 321.1234567890123}
+                                                  "first_touch_stream_nt_gbs": 321.1234567890123, "stream_gbs": 4321.123456789012,
+                                                  "rows_gbs": 4321.123456789012}
+    kern = {"power_w": 1334.1234567890123, "sclk_mhz_hwmon": 2204.1234567890123, "fclk_mhz_dpm": 1250.1234567890123}
+    line["config"]["device"]["power"] = {"static": {"power_cap_w": 1400.1234567890123, "perf_level": "auto"}, "f32": kern, "f16x3": kern, "bf16x3": kern}
     line["eager_rocm"].update(kind="reference", port={"value": 255026.83364130167})
     line["tiny"]["cpu_baseline"].update(kind="reference")
     line["summary"] = B.summary_of(line)
@@ -215,7 +218,8 @@ def test_bench_compact_line_fits_the_driver_record():
     assert all(not isinstance(v, (dict, list)) for k, v in c["roofline"].items())
     assert abs(c["value"] - line["value"]) <= 1e-5 * line["value"] and c["roofline"]["frac"] == round(line["roofline"]["frac"], 6)
     for k in ("train_ms_per_iter_bf16x3", "train_bf16x3_fwd_save_ms_at_2400mhz", "split_f16_rays_s", "pattern_store_gbs", "product_over_eager",
-              "launcher_eval_frames_s", "launcher_gpu_s_per_frame", "eager_rocm_kind", "tiny_cpu_kind"):
+              "launcher_eval_frames_s", "launcher_gpu_s_per_frame", "eager_rocm_kind", "tiny_cpu_kind", "power_cap_w", "power_w_f16x3",
+              "sclk_mhz_f16x3", "pattern_store_default_policy_gbs"):
         assert k in c["summary"], k
     # an overgrown summary sheds keys from the back instead of breaking the record
     line["summary"].update({f"pad_{i}": "x" * 40 for i in range(200)})
@@ -431,9 +435,47 @@ def test_hot_kernels_keep_their_register_and_instruction_budget(tmp_path):
     assert len(re.findall(r"buffer_load_dwordx4 .* lds", k["body"])) >= 24 and "global_load_lds" not in k["body"]
 
 
+def test_branch_free_sincos_on_the_host():
+    """csrc/nf_sincos.h (the in-kernel positional encoding's sin / cos pair) uses IEEE operations only -- explicit fused multiply-adds,
+    round-to-nearest-even, integer bit operations -- so the device computes the bits the host computes: compile the SAME header with gcc
+    and sweep it against double precision.  Gate: 1.2e-7 up to |x| = 2^20 (an encoding argument 2^9 * coordinate), 2e-7 up to 2^23,
+    4e-6 up to 2^27; SURVEY 8(d)(i) asks 2e-6 of the encoding."""
+    import subprocess, tempfile
+    src = r'''
+#include "nf_sincos.h"
+#include <stdio.h>
+int main(void) {
+    for (int e = -24; e <= 27; ++e) {
+        double ws = 0, wc = 0;
+        for (int i = 0; i < 400000; ++i) {
+            float x = ldexpf(1.0f + (float)i / 400000.0f, e) * ((i & 1) ? -1.f : 1.f), s, c;
+            nf_sincos(x, &s, &c);
+            double es = fabs((double)s - sin((double)x)), ec = fabs((double)c - cos((double)x));
+            if (es > ws) ws = es;
+            if (ec > wc) wc = ec;
+        }
+        printf("%d %.4e %.4e\n", e, ws, wc);
+    }
+    float s, c; nf_sincos(0.0f, &s, &c); printf("zero %g %g\n", s, c);
+    return 0;
+}'''
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        exe = os.path.join(td, "t")
+        subprocess.run(["gcc", "-O2", "-ffp-contract=off", "-I", os.path.join(ROOT, "4d-facial-avatars_amd", "csrc"), "-o", exe, os.path.join(td, "t.c"), "-lm"],
+                       check=True)
+        out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split("\n")
+    rows = [l.split() for l in out if l and not l.startswith("zero")]
+    assert len(rows) == 52
+    for e, ws, wc in rows:
+        gate = 1.2e-7 if int(e) < 20 else (2e-7 if int(e) < 23 else 4e-6)
+        assert float(ws) <= gate and float(wc) <= gate, (e, ws, wc)
+    assert [l for l in out if l.startswith("zero")] == ["zero 0 1"]
+
+
 def test_no_kernel_of_the_library_spills(hip_lib):
     """Every kernel of libnerface_hip.so, as the compiler reports it when the library is built (-Rpass-analysis=kernel-resource-usage,
-    kept per translation unit in lib/obj/<unit>.usage.txt): no spilled vector registers, no scratch memory, at most 512 VGPRs + AGPRs."""
+    kept per translation unit in lib/obj/<unit>.usage.txt): no spilled vector OR scalar registers, no scratch memory, at most 512 VGPRs + AGPRs."""
     sys.path.insert(0, os.path.join(ROOT, "4d-facial-avatars_amd"))
     import build
     obj = os.path.join(build.OUT_DIR, "obj")
@@ -441,7 +483,6 @@ def test_no_kernel_of_the_library_spills(hip_lib):
     if not all(os.path.exists(os.path.join(obj, u)) for u in units):
         build.build(force=True, verbose=False)               # objects cached from before the remarks were kept
     n = 0
-    sgpr_spills = {}
     for u in units:
         name = None
         for ln in open(os.path.join(obj, u)):
@@ -451,17 +492,10 @@ def test_no_kernel_of_the_library_spills(hip_lib):
             key, val = m.groups()
             if key == "Function Name":
                 name, n = val, n + 1
-            elif key in ("ScratchSize [bytes/lane]", "VGPRs Spill"):
+            elif key in ("ScratchSize [bytes/lane]", "VGPRs Spill", "SGPRs Spill"):
+                # round 5: scalar spills too (round 4 had 38 in the headline kernel -- 32 hoisted lane masks of the per-slot coordinate
+                # selection of the positional encoding, not, as DESIGN r04 said, sincosf's branches -- and 29 in k_grad_reduce)
                 assert int(val) == 0, (u, name, key, val)
-            elif key == "SGPRs Spill":
-                # scalar spills go to VGPR lanes (v_writelane / v_readlane outside the K loops: descriptors and layer constants of the
-                # exact-f32 kernels), never to memory; reported, and bounded so that a regression shows (round 4: 38 in the
-                # headline kernel k_paper_mlp_fwd<2>, 29 in three training kernels, 0 in the other 77)
-                if int(val):
-                    sgpr_spills[name] = int(val)
-                assert int(val) <= 48, (u, name, key, val)
             elif key in ("VGPRs", "AGPRs"):
                 assert int(val) <= 512, (u, name, key, val)
     assert n >= 70, n                                           # 79 kernels in round 3
-    print("kernels with scalar-register spills (to VGPR lanes):", sgpr_spills)
-    assert len(sgpr_spills) <= 6, sgpr_spills
