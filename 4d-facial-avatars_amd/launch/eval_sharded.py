@@ -99,7 +99,7 @@ def _main(argv=None):
                     help="also write the photometric error map of EV:160-182, 492-497 (savedir/error): per-pixel L2 distance to the "
                          "test image through the jet colour map, at the native resolution (the reference saves a matplotlib figure)")
     ap.add_argument("--save-normals", action="store_true", help="also write the cleaned normal map of EV:469-471 (savedir/normals)")
-    ap.add_argument("--precision", choices=["f32", "f16x3", "bf16x3"], default="f32",
+    ap.add_argument("--precision", choices=["f32", "f16x3", "f16x2", "bf16x3"], default="f32",
                     help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; bf16x3 = split-bf16 kernels, 3x faster, "
                          "within the 1e-4 dB PSNR gate (tests/test_gpu_bf16.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"))

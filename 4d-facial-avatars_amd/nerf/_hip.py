@@ -44,6 +44,7 @@ _PROTOTYPES = {
     "nf_paper_f16_flag_offset": (_Z, []),
     "nf_paper_pack_f16": (C.c_int, [_P, _P, _P]),
     "nf_paper_mlp_fwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_paper_mlp_fwd_f16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "nf_paper_mlp_fwd_train_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_paper_packed_bwd_f16_bytes": (_Z, []),
     "nf_paper_pack_bwd_f16": (C.c_int, [_P, _P, _P]),
@@ -73,6 +74,7 @@ _PROTOTYPES = {
     "nf_lcode_f16_flag_offset": (_Z, []),
     "nf_lcode_pack_f16": (C.c_int, [_P, _P, _P]),
     "nf_lcode_mlp_fwd_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
+    "nf_lcode_mlp_fwd_f16x2": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P]),
     "nf_lcode_mlp_fwd_train_f16": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_f16_bytes": (_Z, []),
     "nf_lcode_pack_bwd_f16": (C.c_int, [_P, _P, _P]),
@@ -126,7 +128,7 @@ _PROTOTYPES = {
 _OPTIONAL = set()
 # the revision of include/nerface_hip.h these prototypes were written for (nf_abi_version() of the library must equal it: a stale
 # .so with other signatures would take e.g. a stream pointer as `saved_f32` without any error)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def lib_path() -> str:

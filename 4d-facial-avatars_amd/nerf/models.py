@@ -75,6 +75,7 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
         packed = hw.get()
         cond = ops.paper_condition(packed, expr, latent, near, far)
         if need_grad:
+            ops.require_trainable_precision()
             prec = ops.get_mlp_precision()
             pb = hw.get_bf16() if prec == "bf16x3" else None
             ph = hw.get_f16() if prec == "f16x3" else None
@@ -91,15 +92,17 @@ class ConditionalBlendshapePaperNeRFModel(torch.nn.Module):
             return raw, (packed, cond, saved, "f16" if ph is not None else pb is not None)
         if ops.get_mlp_precision() == "bf16x3":
             return ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z, rd_view), None
-        if ops.get_mlp_precision() == "f16x3":
+        if ops.get_mlp_precision() in ops.F16_MODES:
             key = (hw._signature()[1:], expr.data_ptr(), latent.data_ptr(), expr._version, latent._version)
             if getattr(self, "_f16_probe_key", None) != key:      # once per (weights, conditioning): i.e. once per frame and model
                 amax = ops.f16_preflight(self, ro, rd, z, rd_view, expr, latent, near, far)
                 if not amax * ops.F16_PREFLIGHT_MARGIN < ops.F16_ACT_LIMIT:
-                    raise RuntimeError(f'nerf.set_mlp_precision("f16x3"): hidden activations of {type(self).__name__} reach {amax:.3g} on a '
+                    raise RuntimeError(f'nerf.set_mlp_precision("{ops.get_mlp_precision()}"): hidden activations of {type(self).__name__} reach {amax:.3g} on a '
                                        f'sample of this frame, within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit '
                                        f'({ops.F16_ACT_LIMIT:g}) -- render this model with "f32" or "bf16x3"')
                 self._f16_probe_key = key
+            if ops.get_mlp_precision() == "f16x2":
+                return ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro, rd, z, rd_view), None
             return ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z, rd_view), None
         return ops.paper_mlp_fwd(packed, cond, ro, rd, z, rd_view), None
 
@@ -280,7 +283,7 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                 if ops.get_mlp_precision() == "bf16x3":
                     H.check(lib.nf_lcode_mlp_fwd_bf16(H.ptr(self._hip_packed_bf16()), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
                                                       H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_bf16")
-                elif ops.get_mlp_precision() == "f16x3":
+                elif ops.get_mlp_precision() in ops.F16_MODES:
                     key = (tuple((int(p.data_ptr()), int(p._version)) for p in self.hip_param_list()), expr.data_ptr(), latent.data_ptr(),
                            expr._version, latent._version)
                     if getattr(self, "_f16_probe_key", None) != key:      # once per (weights, conditioning): once per frame and model
@@ -290,12 +293,14 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
                                                f'on a sample of this frame, within {ops.F16_PREFLIGHT_MARGIN:g}x of the fp16 range limit '
                                                f'({ops.F16_ACT_LIMIT:g}) -- render this model with "f32" or "bf16x3"')
                         self._f16_probe_key = key
-                    H.check(lib.nf_lcode_mlp_fwd_f16(H.ptr(self._hip_pack("f16")), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
-                                                     H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_f16")
+                    fwd16 = lib.nf_lcode_mlp_fwd_f16x2 if ops.get_mlp_precision() == "f16x2" else lib.nf_lcode_mlp_fwd_f16
+                    H.check(fwd16(H.ptr(self._hip_pack("f16")), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view),
+                                  H.ptr(z), n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd_f16[x2]")
                 else:
                     H.check(lib.nf_lcode_mlp_fwd(H.ptr(packed), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z), n_rays,
                                                  n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_lcode_mlp_fwd")
                 return raw, None
+            ops.require_trainable_precision()
             prec = ops.get_mlp_precision()
             split = "f16" if prec == "f16x3" else prec == "bf16x3"
             saved = torch.empty(lib.nf_lcode_saved_floats(n_rays * n_samples), dtype=torch.float32, device=dev)

@@ -30,7 +30,12 @@ PAPER_KEYS = (
 # "f16x3" = split-fp16: the same three-MFMA scheme on fp16 pairs (22 operand bits, per-layer power-of-two weight scales,
 # per-point block-floating-point gradient scales): fp32-class accuracy at the bf16x3 speed, for inference and for all three training GEMM kernels
 # of both model families.
-_VALID_PRECISIONS = ("f32", "bf16x3", "f16x3")
+# "f16x2" (round 5): INFERENCE only -- the split-fp16 kernel with two products per weight (W_hi x_hi + W_lo x_hi: activations enter with
+# fp16's 11 bits, weights keep 22), a third fewer MFMAs than "f16x3"; whole frames stay within 1e-4 dB PSNR of the reference (measured
+# 5e-6 .. 1e-5 dB), per-point outputs carry 2^-12 relative rounding.  A training step under "f16x2" raises (train with "f16x3").
+_VALID_PRECISIONS = ("f32", "bf16x3", "f16x3", "f16x2")
+F16_MODES = ("f16x3", "f16x2")           # arithmetics that run on the scaled fp16 weight stream (range probe + range flag apply)
+INFERENCE_ONLY_PRECISIONS = ("f16x2",)
 _mlp_precision = os.environ.get("NERFACE_MLP_PRECISION", "f32")
 
 
@@ -330,6 +335,23 @@ def paper_mlp_fwd_f16(packed_h, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
     return raw
 
 
+def paper_mlp_fwd_f16x2(packed_h, cond, ro, rd, z, rd_view=None) -> torch.Tensor:
+    """"f16x2" forward: the split-fp16 kernel with two products per weight (csrc/nf_mlp_f16x2.hip) on the SAME packed image as f16x3."""
+    dev = H.require_device(cond, ro, rd, z, rd_view)
+    n_rays, n_samples = z.shape
+    raw = torch.empty((n_rays, n_samples, 4), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        H.check(H.lib().nf_paper_mlp_fwd_f16x2(H.ptr(packed_h), H.ptr(cond), H.ptr(ro), H.ptr(rd), H.ptr(rd_view), H.ptr(z),
+                                               n_rays, n_samples, H.ptr(raw), H.stream_ptr(dev)), "nf_paper_mlp_fwd_f16x2")
+    return raw
+
+
+def require_trainable_precision() -> None:
+    """A training step (need_grad) under an inference-only arithmetic is refused, not silently run on another one."""
+    if _mlp_precision in INFERENCE_ONLY_PRECISIONS:
+        raise RuntimeError(f'nerf.set_mlp_precision("{_mlp_precision}") is an inference arithmetic: train with "f32", "f16x3" or "bf16x3"')
+
+
 _f16_train_probe_every = [128]           # training: the f32 range probe runs on a model's first forward and every n-th after it
 
 
@@ -379,8 +401,8 @@ def check_f16_range(*models, sync_ranks: bool = False) -> None:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             dist.all_reduce(total, op=dist.ReduceOp.MAX)
     if int(total.item()) != 0:
-        raise RuntimeError('nerf.set_mlp_precision("f16x3"): an activation left the fp16 range (|x| >= 4094) and a density output is not '
-                           'finite -- render this model with "f32" or "bf16x3"')
+        raise RuntimeError(f'nerf.set_mlp_precision("{_mlp_precision}"): an activation left the fp16 range (|x| >= 4094) and a density output is '
+                           'not finite -- render this model with "f32" or "bf16x3"')
 
 
 def paper_mlp_fwd_train(packed, cond, ro, rd, z, rd_view=None, packed_b=None, packed_h=None):

@@ -240,7 +240,7 @@ def run_one_iter_of_nerf(height, width, focal_length, model_coarse, model_fine, 
         ]
     synthesized = list(zip(*pred))
     synthesized = [(img[0] if len(img) == 1 else torch.cat(img, dim=0)) if img[0] is not None else None for img in synthesized]
-    if ops.get_mlp_precision() == "f16x3" and not torch.is_grad_enabled():
+    if ops.get_mlp_precision() in ops.F16_MODES and not torch.is_grad_enabled():
         ops.check_f16_range(model_coarse, model_fine)              # once per call (per frame in validation mode), after all chunks
     if mode == "validation":
         synthesized = [img.view(shape) if img is not None else None for (img, shape) in zip(synthesized, restore_shapes)]

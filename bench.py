@@ -197,7 +197,7 @@ def cpu_baseline(n_rays=12288):
         from tests import util as U
         tgt = C.ray_subset(H, W, 3, n_rays, seed=5)[3]
         keep = nerf.get_mlp_precision()
-        for prec in ("bf16x3", "f16x3", "f32"):
+        for prec in ("bf16x3", "f16x3", "f16x2", "f32"):
             nerf.set_mlp_precision(prec)
             out, *_ = U.run_product(nerf, c, torch.device("cuda", torch.cuda.current_device()))
             parity[prec] = {"abs_dpsnr_db_fine": abs(O.psnr(out[3].cpu(), tgt) - O.psnr(ref[3], tgt)),
@@ -219,6 +219,7 @@ def cpu_baseline(n_rays=12288):
         dv = lambda t: t.to(dev).contiguous()
         got = {"f32": ops.paper_mlp_fwd(hw.get(), cond, dv(r0), dv(d0), dv(zz)),
                "f16x3": ops.paper_mlp_fwd_f16(hw.get_f16(), cond, dv(r0), dv(d0), dv(zz)),
+               "f16x2": ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, dv(r0), dv(d0), dv(zz)),
                "bf16x3": ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, dv(r0), dv(d0), dv(zz))}
         parity["mlp_rms_error_vs_fp64"] = {k: (v.cpu().double() - want).pow(2).mean(dim=(0, 1)).sqrt().tolist() for k, v in got.items()}
         parity["mlp_output_scale"] = want.abs().amax(dim=(0, 1)).tolist()
@@ -893,7 +894,7 @@ def pmc_sustained_clock(precision="f32", timeout=240):
     prof, why = _pmc_guard()
     if prof is None:
         return None, why
-    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
+    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16", "f16x2": "k_paper_mlp_fwd_f16x2"}.get(precision, "k_paper_mlp_fwd<")
     tmp = tempfile.mkdtemp(prefix="nf_pmc_")
     try:
         rows, err = pmc_pass_rows(prof, tmp, "GRBM_GUI_ACTIVE", "pmc_one_launch.py", [precision], timeout)
@@ -919,7 +920,7 @@ def pmc_traffic(precision, timeout=240):
     """HBM bytes per fine-pass MLP launch of the eval kernel of `precision` (tools/pmc_one_launch.py launches exactly the kernel
     the roofline object times).  Raw counters, no 2x correction (the dominant reads are 4-byte z loads, not the 16 B/lane stream
     the guide's correction is calibrated on).  Returns (bytes or None, detail dict)."""
-    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16"}.get(precision, "k_paper_mlp_fwd<")
+    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16", "f16x2": "k_paper_mlp_fwd_f16x2"}.get(precision, "k_paper_mlp_fwd<")
     got, detail = pmc_kernel_bytes("pmc_one_launch.py", [precision], [kernel], timeout)
     if got is None:
         return None, detail
@@ -1001,7 +1002,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only (skip split_bf16 / train / tiny / PMC traffic)")
-    ap.add_argument("--precision", choices=["bf16x3", "f16x3", "f32"], default="f32",
+    ap.add_argument("--precision", choices=["bf16x3", "f16x3", "f16x2", "f32"], default="f32",
                     help="arithmetic of the HEADLINE: f32 (default) = exact-f32 MFMA, the reference's arithmetic; f16x3 = split-fp16 "
                          "(3 fp16 MFMAs per product on scaled weights, f32 accumulate: error against fp64 at the exact-f32 kernel's "
                          "level); bf16x3 = split-bf16 (passes the 1e-4 dB PSNR gate).  The others are reported beside it "
@@ -1104,8 +1105,9 @@ def main():
     dt = timed_frames()
     rays_total = world * args.steps * H * W
     dtype_of = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 products, f32 accumulate)",
-                "f16x3": "f16x3 (split-fp16 products on scaled weights, f32 accumulate; fp32-class error)"}
-    key_of = {"f32": "exact_f32", "bf16x3": "split_bf16", "f16x3": "split_f16"}
+                "f16x3": "f16x3 (split-fp16 products on scaled weights, f32 accumulate; fp32-class error)",
+                "f16x2": "f16x2 (two fp16 products per weight: 11-bit activations, 22-bit weights, f32 accumulate; inference only)"}
+    key_of = {"f32": "exact_f32", "bf16x3": "split_bf16", "f16x3": "split_f16", "f16x2": "split_f16x2"}
     line = {
         "metric": "rays/sec at 512x512, 64 coarse + 128 fine samples", "value": rays_total / dt, "unit": "rays/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / max(args.steps, 1),
@@ -1118,7 +1120,7 @@ def main():
     }
 
     # ---- the same K frames (same warm-up, same bracketing) in the other arithmetics, beside the headline -----------------
-    others = [p for p in ("f32", "f16x3", "bf16x3") if p != args.precision]
+    others = [p for p in ("f32", "f16x3", "f16x2", "bf16x3") if p != args.precision]
     if not args.no_extras:
         for other in others:
             nerf.set_mlp_precision(other)
@@ -1128,6 +1130,26 @@ def main():
                 "warmup": args.warmup, "dtype": dtype_of[other],
                 "note": f"same workload, frames and timing protocol with nerf.set_mlp_precision('{other}')"}
         nerf.set_mlp_precision(args.precision)
+        if rank == 0 and args.precision == "f32":
+            # the whole timed frame 0 (262,144 rays, the same draws: seeded) in every other arithmetic against the exact-f32 product frame:
+            # north_star's gate on the workload itself (|PSNR(., target) - PSNR(f32 frame, target)|, target = random image) and the self-PSNR
+            try:
+                tgt = torch.rand((H, W, 3), generator=torch.Generator().manual_seed(11)).to(dev).double()
+                psnr = lambda a, b: -10.0 * float(torch.log10(torch.mean((a - b) ** 2)))
+                frames = {}
+                for prec in [args.precision] + others:
+                    nerf.set_mlp_precision(prec)
+                    torch.manual_seed(4321)
+                    frames[prec] = step(0)[3].double()
+                for other in others:
+                    line[key_of[other]]["whole_frame_vs_exact_f32"] = {
+                        "abs_dpsnr_db": abs(psnr(frames[other], tgt) - psnr(frames["f32"], tgt)), "self_psnr_db": psnr(frames[other], frames["f32"]),
+                        "max_abs_rgb_diff": float((frames[other] - frames["f32"]).abs().max()), "rays": H * W}
+                del frames
+            except Exception as e:                                # an extra must never cost the headline
+                line["whole_frame_parity_error"] = repr(e)
+            nerf.set_mlp_precision(args.precision)
+            torch.manual_seed(1234 + rank)
 
     # ---- configs[2] (N>1: configs[4]): training iterations in both arithmetics --------------------------------------------
     if not args.no_extras:
@@ -1179,7 +1201,8 @@ def main():
         pk_h = model_f.hip_weights().get_f16()
         ms = {"f32": timed(lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
               "bf16x3": timed(lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z)),
-              "f16x3": timed(lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z))}
+              "f16x3": timed(lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z)),
+              "f16x2": timed(lambda: ops.paper_mlp_fwd_f16x2(pk_h, cond, ro, rd, z))}
         exe_f32 = float(CHUNK) * S * EXEC_FLOP_PER_POINT_F32 / (ms["f32"] * 1e-3) / 1e12
         objs = {"f32": {"bound": "mfma", "kernel": "k_paper_mlp_fwd<2> (65536 rays x 192 samples per launch)",
                         "achieved": flops / (ms["f32"] * 1e-3) / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -1196,22 +1219,23 @@ def main():
                                 "frac_at_sustained_clock = executed FLOPs / (busy cycles of ONE PMC dispatch x 256 CUs x 256 FLOP/clk): cycles and "
                                 "FLOPs of the same launch (GRBM_GUI_ACTIVE, a PMC pass of this run)",
                         "note_short": "frac = issued MFMA FLOPs (999,936/pt) / peak at 2.4 GHz; frac_algorithmic counts 1,100,032/pt"}}
-        for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16")):
+        for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16"),
+                                       ("f16x2", "k_paper_mlp_fwd_f16x2", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
-            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT / (ms[prec] * 1e-3) / 1e12
+            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT * (2008.0 / 3012.0 if prec == "f16x2" else 1.0) / (ms[prec] * 1e-3) / 1e12
             objs[prec] = {"bound": "mfma", "kernel": f"{kname} (65536 rays x 192 samples per launch)",
                           "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                           "avg_launch_ms": ms[prec], "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes,
                           "traffic": None, "executed_tflops": exe, "frac_executed": exe / PEAK_BF16_MFMA_TFLOPS,
-                          "note": f"achieved counts ALGORITHMIC f32 FLOPs (1,100,032/point); each costs 3 {peak_name} MFMA FLOPs in the split "
-                                  f"scheme, so frac (against the dense {peak_name} peak) cannot exceed 1/3; executed_* counts the issued MFMA FLOPs"
+                          "note": f"achieved counts ALGORITHMIC f32 FLOPs (1,100,032/point); each costs {2 if prec == 'f16x2' else 3} {peak_name} MFMA FLOPs in the split "
+                                  f"scheme, so frac (against the dense {peak_name} peak) cannot exceed 1/{2 if prec == 'f16x2' else 3}; executed_* counts the issued MFMA FLOPs"
                                   + ("; against the fp32-MFMA peak (157.3 TFLOP/s) the same algorithmic rate is "
                                      f"{ach / PEAK_F32_MFMA_TFLOPS:.2f}x -- fp32-class results faster than the fp32 matrix pipe can issue them"
                                      if prec == "f16x3" else "")}
         if world == 1 and not args.no_extras:
             for prec in ("f32", "f16x3", "bf16x3"):
                 objs[prec]["traffic"], objs[prec]["traffic_detail"] = pmc_traffic(prec)
-            for prec in ("f16x3", "bf16x3"):
+            for prec in ("f16x3", "f16x2", "bf16x3"):
                 objs[prec]["sustained_clock_mhz"], objs[prec]["sustained_clock_detail"] = pmc_sustained_clock(prec)
                 if objs[prec]["sustained_clock_mhz"]:
                     objs[prec]["frac_executed_at_sustained_clock"] = objs[prec]["frac_executed"] * 2400.0 / objs[prec]["sustained_clock_mhz"]
@@ -1264,6 +1288,7 @@ def main():
             try:
                 line["config"]["device"]["power"] = power_probe(dev, (("f32", lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
                                                                       ("f16x3", lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z)),
+                                                                      ("f16x2", lambda: ops.paper_mlp_fwd_f16x2(pk_h, cond, ro, rd, z)),
                                                                       ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z))))
             except Exception as e:
                 line["config"]["device"]["power"] = {"error": repr(e)}
@@ -1353,6 +1378,12 @@ def summary_of(line):
          "split_bf16_fine_launch_ms": g("split_bf16", "roofline", "avg_launch_ms"),
          "split_f16_clock_mhz": g("split_f16", "roofline", "sustained_clock_mhz"),
          "split_bf16_clock_mhz": g("split_bf16", "roofline", "sustained_clock_mhz"),
+         "split_f16x2_rays_s": g("split_f16x2", "value"), "split_f16x2_fine_launch_ms": g("split_f16x2", "roofline", "avg_launch_ms"),
+         "split_f16x2_clock_mhz": g("split_f16x2", "roofline", "sustained_clock_mhz"),
+         "split_f16x2_frac_executed": g("split_f16x2", "roofline", "frac_executed"),
+         "split_f16x2_over_eager": None,
+         "split_f16x2_frame_abs_dpsnr_db": g("split_f16x2", "whole_frame_vs_exact_f32", "abs_dpsnr_db"),
+         "split_f16x2_frame_self_psnr_db": g("split_f16x2", "whole_frame_vs_exact_f32", "self_psnr_db"),
          "split_f16_frac_executed": g("split_f16", "roofline", "frac_executed"),
          "split_bf16_frac_executed": g("split_bf16", "roofline", "frac_executed")}
     for prec in ("f32", "f16x3", "bf16x3"):
@@ -1377,16 +1408,19 @@ def summary_of(line):
               "cpu_baseline_rays_s": g("cpu_baseline", "value"), "cpu_baseline_kind": g("cpu_baseline", "kind"),
               "abs_dpsnr_db_f32": g("cpu_baseline", "parity_on_sample", "f32", "abs_dpsnr_db_fine"),
               "abs_dpsnr_db_f16x3": g("cpu_baseline", "parity_on_sample", "f16x3", "abs_dpsnr_db_fine"),
+              "abs_dpsnr_db_f16x2": g("cpu_baseline", "parity_on_sample", "f16x2", "abs_dpsnr_db_fine"),
               "abs_dpsnr_db_bf16x3": g("cpu_baseline", "parity_on_sample", "bf16x3", "abs_dpsnr_db_fine"),
               "tiny_rays_s": g("tiny", "value"), "tiny_cpu_rays_s": g("tiny", "cpu_baseline", "value"),
               "tiny_cpu_kind": g("tiny", "cpu_baseline", "kind"),
               "launcher_eval_frames_s": g("launcher", "launcher_eval_frames_s"),
               "launcher_gpu_s_per_frame": g("launcher", "launcher_gpu_s_per_frame"),
               "launcher_wall_over_gpu": g("launcher", "launcher_wall_over_gpu")})
+    if s.get("split_f16x2_rays_s") and s.get("eager_rocm_rays_s"):
+        s["split_f16x2_over_eager"] = s["split_f16x2_rays_s"] / s["eager_rocm_rays_s"]       # north_star's ratio on its fastest gate-keeping arithmetic
     pw = g("config", "device", "power") or {}
     st = pw.get("static") or {}
     s.update({"power_cap_w": st.get("power_cap_w"), "perf_level": st.get("perf_level")})
-    for prec in ("f32", "f16x3", "bf16x3"):                          # how THIS box holds its power cap under each inference kernel
+    for prec in ("f32", "f16x3", "f16x2", "bf16x3"):                 # how THIS box holds its power cap under each inference kernel
         o = pw.get(prec) or {}
         s.update({f"power_w_{prec}": o.get("power_w"), f"sclk_mhz_{prec}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm"),
                   f"fclk_mhz_{prec}": o.get("fclk_mhz_dpm")})

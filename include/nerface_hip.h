@@ -27,7 +27,7 @@ typedef void* nf_stream_t; /* hipStream_t */
 #define NF_EINVAL (-22)
 
 /* ---- library ------------------------------------------------------------------------------------ */
-int         nf_abi_version(void);            /* bumped on any signature / layout change; now 2        */
+int         nf_abi_version(void);            /* bumped on any signature / layout change; now 3        */
 const char* nf_error_string(int code);
 const char* nf_build_info(void);             /* "gfx950 <compiler> <date>"                            */
 
@@ -121,6 +121,12 @@ size_t nf_paper_packed_f16_bytes(void);
 int nf_paper_pack_f16(const float* const* params, void* stream_out, nf_stream_t stream);
 int nf_paper_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+/* "f16x2" (round 5, csrc/nf_mlp_f16x2.hip): the same call on the same packed image with TWO fp16 products per weight -- activations enter
+ * with their 11-bit `hi` half only, weights keep 22 bits: W_hi x_hi + W_lo x_hi, a third fewer MFMAs.  Inference only.  Whole 512 x 512
+ * frames stay within north_star's 1e-4 dB of the reference (measured 5e-6 .. 1e-5 dB, self-PSNR 91 .. 115 dB); per-point outputs carry
+ * fp16's 2^-12 relative rounding of the activations (profiles/r05_split_products.md).  Range and range guard as nf_paper_mlp_fwd_f16. */
+int nf_paper_mlp_fwd_f16x2(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                           const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
 /* training on the split-fp16 kernels ("f16x3": the three training GEMM kernels -- activation-saving forward, dX chain,
  * weight-gradient GEMMs -- at fp32-class accuracy on the 16-bit matrix pipe).  nf_paper_mlp_fwd_train_f16 fills `saved` like
  * nf_paper_mlp_fwd_train_bf16; nf_paper_mlp_bwd_f16 = nf_paper_mlp_bwd with the chain and the dW GEMMs on fp16 pairs, gradients
@@ -212,6 +218,8 @@ size_t nf_lcode_f16_flag_offset(void);
 int nf_lcode_pack_f16(const float* const* params, void* stream_out, nf_stream_t stream);
 int nf_lcode_mlp_fwd_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+int nf_lcode_mlp_fwd_f16x2(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
+                           const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);   /* "f16x2": see nf_paper_mlp_fwd_f16x2 */
 /* training the second family on the split-fp16 kernels (as nf_paper_mlp_fwd_train_f16 / nf_paper_mlp_bwd_f16) */
 int nf_lcode_mlp_fwd_train_f16(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                                const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);

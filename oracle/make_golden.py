@@ -345,8 +345,6 @@ def main():
     names7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
     only = sys.argv[2:] if len(sys.argv) > 2 and sys.argv[1] == "cases" else None     # `cases NAME...`: only these 7-tuple fixtures
     for name in (only or C.CASES):
-        if name == NOFLIP:                                            # gradient fixture only (make_soft_grads)
-            continue
         c = C.build_case(name)
         out_ref, _ = run_reference(ref, c)
         st = {}

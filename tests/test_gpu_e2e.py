@@ -303,7 +303,7 @@ def test_full_frame_512_properties(hip_lib, gpu, precision):
 
 @pytest.mark.parametrize("family", ["hard", "soft"])
 def test_full_frame_512_vs_fp64_oracle(hip_lib, gpu, family):
-    """BASELINE configs[1], the WHOLE frame: all 262,144 rays x (64 + 128) samples through the product in all three arithmetics
+    """BASELINE configs[1], the WHOLE frame: all 262,144 rays x (64 + 128) samples through the product in all four arithmetics
     against the oracle evaluated in float64 on the device (oracle code, torch ops; tests/util.py).  north_star gate:
     |PSNR(ours, target) - PSNR(oracle, target)| <= 1e-4 dB for the coarse and the fine image; self-PSNR and max|d rgb| are
     reported.  "hard" = the x1000 density head of the golden cases, "soft" = SURVEY §8(d)'s x40 head."""
@@ -319,7 +319,7 @@ def test_full_frame_512_vs_fp64_oracle(hip_lib, gpu, family):
     mc, mf = U.make_model(nerf, c["p_coarse"], gpu), U.make_model(nerf, c["p_fine"], gpu)
     ex, ed = U.encoders(nerf)
     psnr = lambda a, b: float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))
-    for precision in ("f32", "f16x3", "bf16x3"):
+    for precision in ("f32", "f16x3", "f16x2", "bf16x3"):
         nerf.set_mlp_precision(precision)
         with torch.no_grad():
             out = nerf.run_one_iter_of_nerf(H, W, None, mc, mf, ro, rd, U.make_options(nerf, 64, 128, False, 0.0), mode="validation",
@@ -355,7 +355,7 @@ def test_full_frame_512_stochastic_vs_fp64_oracle(hip_lib, gpu, family):
     ex, ed = U.encoders(nerf)
     psnr = lambda a, b: float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))
     try:
-        for precision in ("f32", "f16x3", "bf16x3"):
+        for precision in ("f32", "f16x3", "f16x2", "bf16x3"):
             nerf.set_mlp_precision(precision)
             rands = [t for k in range(0, H * W, chunk) for t in (t_rand[k:k + chunk], u[k:k + chunk])]
             with torch.no_grad(), U.injected_random(rands, []):

@@ -1,0 +1,102 @@
+"""'f16x2' (round 5): the split-fp16 forward with two products per weight (W_hi x_hi + W_lo x_hi), inference only.  GPU only.
+
+SURVEY §8(d) re-gated for this arithmetic, explicitly: (ii) the end-to-end gate of north_star -- |dPSNR| <= 1e-4 dB on whole frames -- is
+held as it stands (tests/test_gpu_e2e.py: test_full_frame_512_vs_fp64_oracle and its perturbed twin run "f16x2" beside the other
+arithmetics; tests/test_gpu_lcode.py the second family); (i) per point, the activations are rounded to fp16's 11 significand bits once
+per layer, so a raw output carries the sum of ~seven layers of 2^-12-class relative errors of its inputs, weighted by the (boosted) head:
+colours (fc_rgb x10): 1e-3 absolute max / 2e-4 rms (measured 2.4e-4 / 5.8e-5) against 2e-5 x scale for f32 / f16x3; density: relative to
+T = sqrt(sum_k (w_alpha_k feat_k)^2), the root-sum-square of the 256 products that make sigma (the x1000 / x40 head enters through w_alpha):
+2e-3 T max / 4e-4 T rms (measured 3e-4 T / 7.5e-5 T on both heads).  Everything else is the f16x3 kernel: same packed image, same range
+guard, deterministic."""
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import nerface_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(nerf, ops, gpu, boost, n_rays=96, s=192):
+    c = C.build_case("eval_det_64_128")
+    g = torch.Generator().manual_seed(5)
+    ro, rd, _, _, _ = C.ray_subset(512, 512, 3, n_rays, 5)
+    z = torch.sort(torch.rand((n_rays, s), generator=g) * 0.6 + 0.2, dim=-1)[0]
+    params = O.init_paper_params(1, boost=boost)
+    m = U.make_model(nerf, params, gpu)
+    hw = m.hip_weights()
+    cond = ops.paper_condition(hw.get(), c["expr"].to(gpu), c["latent"].to(gpu), O.NEAR, O.FAR)
+    p64 = {k: v.double() for k, v in params.items()}
+    acts = []
+    ref = O.paper_mlp(p64, O.encode_points(ro.double(), rd.double(), z.double(), O.NEAR, O.FAR), c["expr"].double(), c["latent"].double(),
+                      acts=acts).reshape(n_rays, s, 4)
+    feat = acts[6]                                                             # (points, 256): fc_feat output (oracle hook)
+    t_sigma = float(((feat ** 2) @ (p64["fc_alpha.weight"] ** 2).t()).sqrt().max())
+    return hw, cond, ro.to(gpu), rd.to(gpu), z.to(gpu), ref, t_sigma
+
+
+@pytest.mark.parametrize("boost", [True, "survey"])
+def test_f16x2_raw_outputs(hip_lib, gpu, boost):
+    import nerf
+    from nerf import ops
+    hw, cond, ro, rd, z, ref, t_sigma = _setup(nerf, ops, gpu, boost)
+    x2 = ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro, rd, z)
+    x3 = ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z)
+    b3 = ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z)
+    scale = ref.abs().amax(dim=(0, 1))
+    err = lambda t: (t.cpu().double() - ref).abs().amax(dim=(0, 1))
+    rms = lambda t: (t.cpu().double() - ref).pow(2).mean(dim=(0, 1)).sqrt()
+    print(f"[boost={boost}] f16x2 max|err| vs fp64 {['%.2e' % v for v in err(x2).tolist()]} rms {['%.2e' % v for v in rms(x2).tolist()]}; "
+          f"f16x3 rms {['%.2e' % v for v in rms(x3).tolist()]}; bf16x3 rms {['%.2e' % v for v in rms(b3).tolist()]} (scale {['%.2g' % v for v in scale.tolist()]})")
+    print(f"    density: T = {t_sigma:.3g}, max err / T = {float(err(x2)[3]) / t_sigma:.2e}, rms / T = {float(rms(x2)[3]) / t_sigma:.2e}")
+    assert torch.all(err(x2)[:3] <= 1e-3) and torch.all(rms(x2)[:3] <= 2e-4)                              # the stated per-point gates of this arithmetic
+    assert float(err(x2)[3]) <= 2e-3 * t_sigma and float(rms(x2)[3]) <= 4e-4 * t_sigma
+    assert torch.all(rms(x3) <= 0.05 * rms(x2))                                                          # (and f16x3 really is another class)
+    assert bool(torch.isfinite(x2).all())
+    assert torch.equal(x2, ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro, rd, z))                       # deterministic
+    # launch invariance: the same points in another launch shape (ragged tail, other workgroup boundaries) give the same bits
+    part = ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro[5:42].contiguous(), rd[5:42].contiguous(), z[5:42].contiguous())
+    assert torch.equal(part, x2[5:42])
+
+
+def test_f16x2_is_inference_only_and_guarded(hip_lib, gpu):
+    """A training step under "f16x2" is refused (no silent switch to another arithmetic); the fp16 range probe and the sticky range flag
+    of the f16x3 path protect this mode as well (same packed image, same kernel body)."""
+    import nerf
+    c = C.build_case("soft_train_rand_64_64")
+    nerf.set_mlp_precision("f16x2")
+    try:
+        with pytest.raises(RuntimeError, match="inference arithmetic"):
+            U.run_product(nerf, c, gpu, mode="train", grad=True)
+        out, *_ = U.run_product(nerf, c, gpu)                                  # no gradient wanted: renders
+        assert bool(torch.isfinite(out[3]).all())
+        bad = C.build_case("eval_det_64_128")
+        bad["p_coarse"] = dict(bad["p_coarse"])
+        bad["p_coarse"]["layers_xyz.1.weight"] = bad["p_coarse"]["layers_xyz.1.weight"] * 2.0 ** 14
+        with pytest.raises(RuntimeError, match="fp16 range"):
+            U.run_product(nerf, bad, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+
+
+@pytest.mark.parametrize("name", ["soft_eval_det_64_128", "soft_train_rand_64_64", "soft_lindisp_rand_16_24"])
+def test_f16x2_against_golden_reference(hip_lib, gpu, name):
+    """The reference's own outputs (tests/golden): 7-tuple of run_one_iter_of_nerf under "f16x2".  Gates stated for this arithmetic:
+    colours 2e-4 (SURVEY's 2e-5 x the 11-bit activations' 2^-12 / f32's 2^-24 would be far looser; measured ~3e-5), acc 1e-5."""
+    import numpy as np, os
+    import nerf
+    c = C.build_case(name)
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", f"{name}.npz"))
+    nerf.set_mlp_precision("f16x2")
+    try:
+        out, *_ = U.run_product(nerf, c, gpu)
+    finally:
+        nerf.set_mlp_precision("f32")
+    worst = {}
+    for n, o in zip(["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"], out):
+        if o is None:
+            continue
+        worst[n] = float(np.abs(o.cpu().numpy() - gold[n]).max())
+    print(f"f16x2 vs reference outputs [{name}]:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert worst["rgb_c"] < 2e-4 and worst["rgb_f"] < 2e-4 and worst["acc_c"] < 1e-5 and worst["acc_f"] < 1e-5 and worst["w_last"] < 2e-4

@@ -223,6 +223,37 @@ def test_lcode_bf16x3_psnr_gate_and_golden(hip_lib, gpu):
         assert abs(p_ref - p_our) <= 1e-4
 
 
+def test_lcode_full_frame_512_vs_fp64_oracle(hip_lib, gpu):
+    """Second model family, the WHOLE 512 x 512 frame (262,144 rays x (64 + 128) samples) in every arithmetic against the oracle evaluated
+    in float64 on the device: north_star's gate |PSNR(ours, target) - PSNR(oracle, target)| <= 1e-4 dB, coarse and fine image."""
+    import nerf
+    c = C.build_case("eval_det_64_128")
+    c["p_coarse"], c["p_fine"] = O.init_lcode_params(5), O.init_lcode_params(6)
+    H = W = 512
+    ro_c, rd_c = O.ray_bundle(H, W, O.INTRINSICS, O.frame_pose(c["frame"]))
+    ro, rd = nerf.get_ray_bundle(H, W, O.INTRINSICS, O.frame_pose(c["frame"]).to(gpu))
+    bg_img, tgt_img = O.synthetic_image(H, W, 7), O.synthetic_image(H, W, 11)
+    ref = U.oracle_render_fp64_on_device(c, ro_c.reshape(-1, 3), rd_c.reshape(-1, 3), bg_img.reshape(-1, 3), gpu, 64, 128, mlp=O.lcode_mlp)
+    tgt = tgt_img.reshape(-1, 3).to(gpu).double()
+    mc, mf = lmodel(nerf, c["p_coarse"], gpu), lmodel(nerf, c["p_fine"], gpu)
+    ex, ed = U.encoders(nerf)
+    psnr = lambda a, b: float(-10.0 * torch.log10(torch.mean((a.double() - b.double()) ** 2)))
+    try:
+        for precision in ("f32", "f16x3", "f16x2", "bf16x3"):
+            nerf.set_mlp_precision(precision)
+            with torch.no_grad():
+                out = nerf.run_one_iter_of_nerf(H, W, None, mc, mf, ro, rd, U.make_options(nerf, 64, 128, False, 0.0), mode="validation",
+                                                encode_position_fn=ex, encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                                background_prior=bg_img.to(gpu).view(-1, 3), latent_code=c["latent"].to(gpu))
+            for k, name in ((0, "rgb_c"), (3, "rgb_f")):
+                ours = out[k].reshape(-1, 3)
+                dp = abs(psnr(ours, tgt) - psnr(ref[k], tgt))
+                print(f"lcode full frame [{precision}] {name}: |dPSNR| = {dp:.2e} dB over 262144 rays, self-PSNR {psnr(ours, ref[k]):.1f} dB")
+                assert dp <= 1e-4, (precision, name, dp)
+    finally:
+        nerf.set_mlp_precision("f32")
+
+
 @pytest.mark.parametrize("n_rays,s", [(8, 64), (3, 7), (40, 192)])
 def test_lcode_f16x3_mlp_meets_the_f32_gate(hip_lib, gpu, n_rays, s):
     """Split-fp16 kernel of the second family: raw outputs against fp64 within the EXACT-f32 kernel's gate and within a small

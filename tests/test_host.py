@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libnerface_hip.so does not export {name}"
     from nerf import _hip
-    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 2          # exact: the ctypes prototypes are written for ONE revision
+    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 3          # exact: the ctypes prototypes are written for ONE revision
     assert b"gfx950" in hip_lib.nf_build_info()
     assert hip_lib.nf_error_string(-22).startswith(b"nerface_hip")
 
@@ -198,8 +198,12 @@ def test_bench_compact_line_fits_the_driver_record():
                                                   "first_touch_stream_nt_gbs": 321.1234567890123, "stream_gbs": 4321.123456789012,
                                                   "rows_gbs": 4321.123456789012}
     kern = {"power_w": 1334.1234567890123, "sclk_mhz_hwmon": 2204.1234567890123, "fclk_mhz_dpm": 1250.1234567890123}
-    line["config"]["device"]["power"] = {"static": {"power_cap_w": 1400.1234567890123, "perf_level": "auto"}, "f32": kern, "f16x3": kern, "bf16x3": kern}
+    line["config"]["device"]["power"] = {"static": {"power_cap_w": 1400.1234567890123, "perf_level": "auto"}, "f32": kern, "f16x3": kern, "f16x2": kern, "bf16x3": kern}
     line["eager_rocm"].update(kind="reference", port={"value": 255026.83364130167})
+    import copy
+    line["split_f16x2"] = copy.deepcopy(line["split_f16"])                 # round 5: the fourth arithmetic
+    line["split_f16x2"]["whole_frame_vs_exact_f32"] = {"abs_dpsnr_db": 3.5123456789012345e-05, "self_psnr_db": 67.41234567890123}
+    line["cpu_baseline"]["parity_on_sample"]["f16x2"] = dict(line["cpu_baseline"]["parity_on_sample"]["f16x3"])
     line["tiny"]["cpu_baseline"].update(kind="reference")
     line["summary"] = B.summary_of(line)
     assert all(v is not None for k, v in line["summary"].items() if k != "train_allreduce_us"), [k for k, v in line["summary"].items() if v is None]
@@ -219,7 +223,7 @@ def test_bench_compact_line_fits_the_driver_record():
     assert abs(c["value"] - line["value"]) <= 1e-5 * line["value"] and c["roofline"]["frac"] == round(line["roofline"]["frac"], 6)
     for k in ("train_ms_per_iter_bf16x3", "train_bf16x3_fwd_save_ms_at_2400mhz", "split_f16_rays_s", "pattern_store_gbs", "product_over_eager",
               "launcher_eval_frames_s", "launcher_gpu_s_per_frame", "eager_rocm_kind", "tiny_cpu_kind", "power_cap_w", "power_w_f16x3",
-              "sclk_mhz_f16x3", "pattern_store_default_policy_gbs"):
+              "sclk_mhz_f16x3", "pattern_store_default_policy_gbs", "split_f16x2_rays_s", "split_f16x2_over_eager", "split_f16x2_frame_abs_dpsnr_db"):
         assert k in c["summary"], k
     # an overgrown summary sheds keys from the back instead of breaking the record
     line["summary"].update({f"pad_{i}": "x" * 40 for i in range(200)})

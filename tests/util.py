@@ -78,9 +78,10 @@ def run_product(nerf, c, device, mode="train", grad=False, chunksize=65536):
     return out, mc, mf, latent
 
 
-def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=4096, stages=None, t_rand=None, u=None):
+def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=4096, stages=None, t_rand=None, u=None, mlp=None):
     """The ORACLE (oracle/nerface_oracle.py: torch ops, no product code) evaluated in float64 on `device`, in ray chunks --
-    the checker for whole 512x512 frames, which the CPU oracle would need minutes for.  Deterministic sampling unless the
+    the checker for whole 512x512 frames, which the CPU oracle would need minutes for (mlp: the model family, default the paper model;
+    c["p_coarse"] / c["p_fine"] are that family's parameters).  Deterministic sampling unless the
     stratified jitter t_rand (R, n_coarse) and the inverse-CDF abscissae u (R, n_fine) are given (the draws the product is fed)."""
     pc = {k: v.to(device=device, dtype=torch.float64) for k, v in c["p_coarse"].items()}
     pf = {k: v.to(device=device, dtype=torch.float64) for k, v in c["p_fine"].items()}
@@ -91,7 +92,7 @@ def oracle_render_fp64_on_device(c, ro, rd, bg, device, n_coarse, n_fine, chunk=
             f = lambda t: None if t is None else t[k:k + chunk].to(device=device, dtype=torch.float64)
             st = {} if stages is not None else None
             parts.append(O.render_rays(pc, pf, f(ro), f(rd), expr, lat, f(bg), O.NEAR, O.FAR, n_coarse, n_fine, t_rand=f(t_rand), u=f(u),
-                                       stages=st))
+                                       stages=st, mlp=mlp))
             if stages is not None:
                 for name, v in st.items():
                     stages.setdefault(name, []).append(v)

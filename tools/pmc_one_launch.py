@@ -22,6 +22,7 @@ ro, rd = ro.view(-1, 3)[:n_rays].contiguous(), rd.view(-1, 3)[:n_rays].contiguou
 z = torch.sort(torch.rand((n_rays, S), device=dev) * 0.6 + 0.2, dim=-1)[0].contiguous()
 for _ in range(3):
     raw = (ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro, rd, z) if prec == "bf16x3" else
-           ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z) if prec == "f16x3" else ops.paper_mlp_fwd(hw.get(), cond, ro, rd, z))
+           ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro, rd, z) if prec == "f16x3" else
+           ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro, rd, z) if prec == "f16x2" else ops.paper_mlp_fwd(hw.get(), cond, ro, rd, z))
 torch.cuda.synchronize()
 print("pmc_one_launch", prec, float(raw[0, 0, 3]))
