@@ -6,7 +6,7 @@ arithmetics; tests/test_gpu_lcode.py the second family); (i) per point, the acti
 per layer, so a raw output carries the sum of ~seven layers of 2^-12-class relative errors of its inputs, weighted by the (boosted) head:
 colours (fc_rgb x10): 1e-3 absolute max / 2e-4 rms (measured 2.4e-4 / 5.8e-5) against 2e-5 x scale for f32 / f16x3; density: relative to
 T = sqrt(sum_k (w_alpha_k feat_k)^2), the root-sum-square of the 256 products that make sigma (the x1000 / x40 head enters through w_alpha):
-2e-3 T max / 4e-4 T rms (measured 3e-4 T / 7.5e-5 T on both heads).  Everything else is the f16x3 kernel: same packed image, same range
+2e-3 T max / 4e-4 T rms (measured 9.5e-4 T / 2.4e-4 T on both heads).  Everything else is the f16x3 kernel: same packed image, same range
 guard, deterministic."""
 import pytest
 import torch

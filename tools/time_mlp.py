@@ -21,10 +21,13 @@ for n_rays, S in ((65536, 192), (65536, 64)):
     ro_, rd_ = ro.view(-1, 3)[:n_rays].contiguous(), rd.view(-1, 3)[:n_rays].contiguous()
     z = torch.sort(torch.rand((n_rays, S), device=dev) * 0.6 + 0.2, dim=-1)[0].contiguous()
     for name, fn in (("f32", lambda: ops.paper_mlp_fwd(hw.get(), cond, ro_, rd_, z)), ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro_, rd_, z)),
-                     ("f16x3", lambda: ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro_, rd_, z))):
+                     ("f16x3", lambda: ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro_, rd_, z)),
+                     ("f16x2", lambda: ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro_, rd_, z))):
         if name == "f32" and os.environ.get("TIME_MLP_SKIP_F32"):
             continue
         if name != "f32" and os.environ.get("TIME_MLP_ONLY_F32"):
+            continue
+        if os.environ.get("TIME_MLP_ONLY") and name != os.environ["TIME_MLP_ONLY"]:
             continue
         fn(); fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
