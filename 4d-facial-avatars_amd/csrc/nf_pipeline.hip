@@ -19,7 +19,8 @@ extern "C" size_t nf_render_rays_workspace_floats(int64_t n_rays, int n_coarse, 
            nf_align64(R * nt * 4);
 }
 
-// split_kind: what the packed_split_* streams are -- 0: (hi, lo) bf16 streams (nf_paper_pack_bf16), 1: fp16 streams (nf_paper_pack_f16)
+// split_kind: what the packed_split_* streams are -- 0: (hi, lo) bf16 streams (nf_paper_pack_bf16), 1: fp16 streams (nf_paper_pack_f16),
+// 2: the same fp16 streams evaluated with two products per weight ("f16x2", nf_mlp_f16x2.hip)
 static int nf_render_rays_impl(int split_kind, const float* packed_coarse, const void* packed_bf16_coarse, const float* packed_fine,
                                   const void* packed_bf16_fine, const float* expr76, const float* latent32, const float* ro,
                                   const float* rd, const float* rd_view, const float* bg, const float* t_vals, const float* t_rand,
@@ -48,7 +49,7 @@ static int nf_render_rays_impl(int split_kind, const float* packed_coarse, const
 #define NF_TRY(call) do { rc = (call); if (rc) return rc; } while (0)
     NF_TRY(nf_paper_condition(packed_coarse, expr76, latent32, near_z, far_z, cond_c, stream));
     NF_TRY(nf_sample_coarse(n_rays, n_coarse, near_z, far_z, t_vals, t_rand, z_c, stream));
-    auto split_fwd = split_kind ? nf_paper_mlp_fwd_f16 : nf_paper_mlp_fwd_bf16;
+    auto split_fwd = split_kind == 2 ? nf_paper_mlp_fwd_f16x2 : (split_kind ? nf_paper_mlp_fwd_f16 : nf_paper_mlp_fwd_bf16);
     if (packed_bf16_coarse) NF_TRY(split_fwd(packed_bf16_coarse, cond_c, ro, rd, rd_view, z_c, n_rays, n_coarse, raw_c, stream));
     else NF_TRY(nf_paper_mlp_fwd(packed_coarse, cond_c, ro, rd, rd_view, z_c, n_rays, n_coarse, raw_c, stream));
     NF_TRY(nf_volume_render_fwd(raw_c, z_c, rd, noise_coarse, bg, n_rays, n_coarse, white_background, rgb_coarse, disp_coarse, acc_coarse,
@@ -92,6 +93,19 @@ extern "C" int nf_render_rays_fwd_f16(const float* packed_coarse, const void* pa
                                       float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
                                       float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream) {
     return nf_render_rays_impl(1, packed_coarse, packed_f16_coarse, packed_fine, packed_f16_fine, expr76, latent32, ro, rd, rd_view, bg, t_vals,
+                               t_rand, u, u_row_stride, noise_coarse, noise_fine, n_rays, n_coarse, n_fine, near_z, far_z, white_background,
+                               workspace, workspace_floats, rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, w_last, stream);
+}
+
+// ... and with two fp16 products per weight ("f16x2"): same streams, same arguments
+extern "C" int nf_render_rays_fwd_f16x2(const float* packed_coarse, const void* packed_f16_coarse, const float* packed_fine,
+                                        const void* packed_f16_fine, const float* expr76, const float* latent32, const float* ro,
+                                        const float* rd, const float* rd_view, const float* bg, const float* t_vals, const float* t_rand,
+                                        const float* u, int64_t u_row_stride, const float* noise_coarse, const float* noise_fine,
+                                        int64_t n_rays, int n_coarse, int n_fine, float near_z, float far_z, int white_background,
+                                        float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
+                                        float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream) {
+    return nf_render_rays_impl(2, packed_coarse, packed_f16_coarse, packed_fine, packed_f16_fine, expr76, latent32, ro, rd, rd_view, bg, t_vals,
                                t_rand, u, u_row_stride, noise_coarse, noise_fine, n_rays, n_coarse, n_fine, near_z, far_z, white_background,
                                workspace, workspace_floats, rgb_coarse, disp_coarse, acc_coarse, rgb_fine, disp_fine, acc_fine, w_last, stream);
 }

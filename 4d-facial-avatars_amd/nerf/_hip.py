@@ -119,6 +119,7 @@ _PROTOTYPES = {
     "nf_render_rays_workspace_floats": (_Z, [_L, _I, _I]),
     "nf_render_rays_fwd": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),
     "nf_render_rays_fwd_f16": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),
+    "nf_render_rays_fwd_f16x2": (C.c_int, [_P] * 13 + [_L, _P, _P, _L, _I, _I, _F, _F, _I, _P, _Z] + [_P] * 7 + [_P]),
     "nf_adam_step": (C.c_int, [_P, _P, _P, _P, _P, _I, _F, _F, _F, _F, _L, _P]),
     "nf_train_loss_fwd": (C.c_int, [_P, _P, _P, _L, _P, _I, _F, _F, _P, _P]),
     "nf_train_loss_bwd": (C.c_int, [_P, _P, _P, _L, _P, _I, _F, _F, _P, _P, _P, _P, _P, _P]),

@@ -330,6 +330,15 @@ int nf_render_rays_fwd_f16(const float* packed_coarse, const void* packed_f16_co
                            float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
                            float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
 
+/* ... and with two fp16 products per weight ("f16x2", nf_paper_mlp_fwd_f16x2): the same streams, the same arguments. */
+int nf_render_rays_fwd_f16x2(const float* packed_coarse, const void* packed_f16_coarse, const float* packed_fine,
+                             const void* packed_f16_fine, const float* expr76, const float* latent32, const float* ro,
+                             const float* rd, const float* rd_view, const float* bg, const float* t_vals, const float* t_rand,
+                             const float* u, int64_t u_row_stride, const float* noise_coarse, const float* noise_fine,
+                             int64_t n_rays, int n_coarse, int n_fine, float near_z, float far_z, int white_background,
+                             float* workspace, size_t workspace_floats, float* rgb_coarse, float* disp_coarse, float* acc_coarse,
+                             float* rgb_fine, float* disp_fine, float* acc_fine, float* w_last, nf_stream_t stream);
+
 /* ---- optimizer step of the trainer -- replaces torch.optim.Adam.step() over [coarse model, fine model, latent codes]
  *      (train_transformed_rays.py:193-199, 391-392) for all tensors in one launch.  Host arrays of n_tensors device pointers
  *      (contiguous f32, numel[i] elements each); step = 1-based count of this update; torch's arithmetic (no weight decay,

@@ -197,15 +197,15 @@ def test_white_background(hip_lib, gpu):
     assert float((d_raw.cpu().double() - raw_l.grad).norm() / raw_l.grad.norm()) < 2e-5
 
 
-@pytest.mark.parametrize("split", [False, True, "f16"])
+@pytest.mark.parametrize("split", [False, True, "f16", "f16x2"])
 def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
-    """nf_render_rays_fwd / nf_render_rays_fwd_f16 (one C call per ray chunk) must reproduce the Python-sequenced kernels bit for bit,
-    in the three arithmetics."""
+    """nf_render_rays_fwd / nf_render_rays_fwd_f16 / _f16x2 (one C call per ray chunk) must reproduce the Python-sequenced kernels bit for
+    bit, in the four arithmetics."""
     import nerf
     from nerf import _hip as H
     from nerf import ops
     c = C.build_case("train_rand_64_64")
-    nerf.set_mlp_precision({False: "f32", True: "bf16x3", "f16": "f16x3"}[split])
+    nerf.set_mlp_precision({False: "f32", True: "bf16x3", "f16": "f16x3", "f16x2": "f16x2"}[split])
     try:
         out_py, mc, mf, _ = U.run_product(nerf, c, gpu)
     finally:
@@ -219,11 +219,11 @@ def test_c_abi_render_rays_fwd_equals_python_pipeline(hip_lib, gpu, split):
             torch.empty(n, device=gpu), torch.empty(n, device=gpu), torch.empty(n, device=gpu)]
     hc, hf = mc.hip_weights(), mf.hip_weights()
     t_vals = ops.linspace01(nc, gpu)
-    stream_of = (lambda h: h.get_f16()) if split == "f16" else ((lambda h: h.get_bf16()) if split else (lambda h: None))
+    stream_of = (lambda h: h.get_f16()) if split in ("f16", "f16x2") else ((lambda h: h.get_bf16()) if split else (lambda h: None))
     args = [hc.get(), stream_of(hc), hf.get(), stream_of(hf), dv(c["expr"]), dv(c["latent"]),
             dv(c["ro"]), dv(c["rd"]), None, dv(c["bg"]), t_vals, dv(c["t_rand"])]
     u, noise_c, noise_f = dv(c["u"]), dv(c["noise_c"]), dv(c["noise_f"])      # keep references: raw pointers do not own memory
-    entry = lib.nf_render_rays_fwd_f16 if split == "f16" else lib.nf_render_rays_fwd
+    entry = {"f16": lib.nf_render_rays_fwd_f16, "f16x2": lib.nf_render_rays_fwd_f16x2}.get(split, lib.nf_render_rays_fwd)
     rc = entry(*[H.ptr(a) for a in args], H.ptr(u), nf, H.ptr(noise_c), H.ptr(noise_f), n, nc, nf,
                                 float(np.float32(O.NEAR)), float(np.float32(O.FAR)), 0, H.ptr(ws), ws_n, *[H.ptr(o) for o in outs],
                                 H.stream_ptr(gpu))
