@@ -100,8 +100,9 @@ def _main(argv=None):
                          "test image through the jet colour map, at the native resolution (the reference saves a matplotlib figure)")
     ap.add_argument("--save-normals", action="store_true", help="also write the cleaned normal map of EV:469-471 (savedir/normals)")
     ap.add_argument("--precision", choices=["f32", "f16x3", "f16x2", "bf16x3"], default="f32",
-                    help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; bf16x3 = split-bf16 kernels, 3x faster, "
-                         "within the 1e-4 dB PSNR gate (tests/test_gpu_bf16.py)")
+                    help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; f16x3 = split-fp16 kernels, fp32-class results, "
+                         "2.7x faster; bf16x3 = split-bf16, 2.9x; f16x2 = two fp16 products per weight, 3.5x -- the last two within the "
+                         "1e-4 dB PSNR gate, not fp32-class per point (tests/test_gpu_bf16.py, tests/test_gpu_f16x2.py)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"))
     ap.add_argument("--as-shipped", action="store_true",
                     help="render exactly what eval_transformed_rays.py renders as shipped (EV:420-446): ablate = 'view_dir' -- pose and "

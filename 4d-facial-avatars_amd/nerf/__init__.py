@@ -20,4 +20,4 @@ from .train_utils import GaussianSmoothing, predict_and_render_radiance, run_net
 from .volume_rendering_utils import *  # noqa: F401,F403
 from .volume_rendering_utils import volume_render_radiance_field
 from .ops import training_loss  # MI355X extension: the trainer's loss (TR:355-387) and its gradients in two launches
-from .ops import get_mlp_precision, set_mlp_precision  # MI355X extension: "f32" (exact) | "bf16x3" (split-bf16 inference)
+from .ops import get_mlp_precision, set_mlp_precision  # MI355X extension: "f32" (exact, default) | "f16x3" | "bf16x3" | "f16x2" (inference only)

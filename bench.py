@@ -1289,7 +1289,11 @@ def main():
                 line["config"]["device"]["power"] = power_probe(dev, (("f32", lambda: ops.paper_mlp_fwd(pk, cond, ro, rd, z)),
                                                                       ("f16x3", lambda: ops.paper_mlp_fwd_f16(pk_h, cond, ro, rd, z)),
                                                                       ("f16x2", lambda: ops.paper_mlp_fwd_f16x2(pk_h, cond, ro, rd, z)),
-                                                                      ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z))))
+                                                                      ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(pk_b, cond, ro, rd, z)),
+                                                                      # the training forward with saves at 262144 points, split-bf16 and exact f32:
+                                                                      # the kernels the driver's boxes of rounds 3 and 4 ran 2.9x / 1.17x slower
+                                                                      ("train_fwd_bf16x3", lambda: ops.paper_mlp_fwd_train(pk, cond, ro[:2048], rd[:2048], z[:2048, :128].contiguous(), packed_b=pk_b)),
+                                                                      ("train_fwd_f32", lambda: ops.paper_mlp_fwd_train(pk, cond, ro[:2048], rd[:2048], z[:2048, :128].contiguous()))))
             except Exception as e:
                 line["config"]["device"]["power"] = {"error": repr(e)}
         line["ranks_seen"] = int(dist.get_world_size()) if dist is not None else 1
@@ -1420,10 +1424,12 @@ def summary_of(line):
     pw = g("config", "device", "power") or {}
     st = pw.get("static") or {}
     s.update({"power_cap_w": st.get("power_cap_w"), "perf_level": st.get("perf_level")})
-    for prec in ("f32", "f16x3", "f16x2", "bf16x3"):                 # how THIS box holds its power cap under each inference kernel
+    for prec in ("f32", "f16x3", "f16x2", "bf16x3", "train_fwd_bf16x3", "train_fwd_f32"):   # how THIS box holds its power cap under each kernel
         o = pw.get(prec) or {}
-        s.update({f"power_w_{prec}": o.get("power_w"), f"sclk_mhz_{prec}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm"),
-                  f"fclk_mhz_{prec}": o.get("fclk_mhz_dpm")})
+        s.update({f"power_w_{prec}": o.get("power_w"), f"sclk_mhz_{prec}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm")})
+        if prec.startswith("train_fwd"):
+            s[f"launch_ms_{prec}"] = o.get("launch_ms")             # back-to-back launches incl. the per-call allocation of `saved` (2.4 GB, cached)
+    s["fclk_mhz"] = (pw.get("f32") or {}).get("fclk_mhz_dpm")
     return s
 
 

@@ -198,7 +198,8 @@ def test_bench_compact_line_fits_the_driver_record():
                                                   "first_touch_stream_nt_gbs": 321.1234567890123, "stream_gbs": 4321.123456789012,
                                                   "rows_gbs": 4321.123456789012}
     kern = {"power_w": 1334.1234567890123, "sclk_mhz_hwmon": 2204.1234567890123, "fclk_mhz_dpm": 1250.1234567890123}
-    line["config"]["device"]["power"] = {"static": {"power_cap_w": 1400.1234567890123, "perf_level": "auto"}, "f32": kern, "f16x3": kern, "f16x2": kern, "bf16x3": kern}
+    line["config"]["device"]["power"] = {"static": {"power_cap_w": 1400.1234567890123, "perf_level": "auto"}, "f32": kern, "f16x3": kern, "f16x2": kern, "bf16x3": kern, "train_fwd_bf16x3": dict(kern, launch_ms=1.1234567890123457),
+                                         "train_fwd_f32": dict(kern, launch_ms=2.1234567890123457)}
     line["eager_rocm"].update(kind="reference", port={"value": 255026.83364130167})
     import copy
     line["split_f16x2"] = copy.deepcopy(line["split_f16"])                 # round 5: the fourth arithmetic
