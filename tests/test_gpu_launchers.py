@@ -84,6 +84,10 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out3, "--precision", "f16x3"]) == [0, 1, 2]
     h = np.asarray(Image.open(os.path.join(out3, "0001.png")))
     assert h.shape == a.shape and h.std() > 0
+    out4 = os.path.join(base, "render_x2")         # "f16x2" (two products per weight): same probe and flag, inference-only arithmetic
+    assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out4, "--precision", "f16x2"]) == [0, 1, 2]
+    x2 = np.asarray(Image.open(os.path.join(out4, "0001.png")))
+    assert x2.shape == a.shape and x2.std() > 0
     assert os.path.exists(os.path.join(out, "disparity", "0002.png"))
 
 
@@ -305,7 +309,7 @@ def test_launchers_second_model_family(hip_lib, gpu, tmp_path):
     moved = [k for k in O.LCODE_KEYS if not torch.equal(ck["model_fine_state_dict"][k], ck0["model_fine_state_dict"][k])]
     assert len(moved) == len(O.LCODE_KEYS), set(O.LCODE_KEYS) - set(moved)        # every tensor of the family receives gradients
     assert float(ck["latent_codes"].abs().sum()) > 0 and np.isfinite(float(ck["loss"]))
-    for prec in ("f32", "bf16x3", "f16x3"):
+    for prec in ("f32", "bf16x3", "f16x3", "f16x2"):
         out = os.path.join(base, "render_" + prec)
         assert eval_sharded.main(["--config", cfg_path, "--checkpoint", os.path.join(logdir, "checkpoint00005.ckpt"), "--savedir", out,
                                   "--precision", prec]) == [0, 1, 2]
