@@ -1233,7 +1233,7 @@ def main():
                                      f"{ach / PEAK_F32_MFMA_TFLOPS:.2f}x -- fp32-class results faster than the fp32 matrix pipe can issue them"
                                      if prec == "f16x3" else "")}
         if world == 1 and not args.no_extras:
-            for prec in ("f32", "f16x3", "bf16x3"):
+            for prec in ("f32", "f16x3", "f16x2", "bf16x3"):
                 objs[prec]["traffic"], objs[prec]["traffic_detail"] = pmc_traffic(prec)
             for prec in ("f16x3", "f16x2", "bf16x3"):
                 objs[prec]["sustained_clock_mhz"], objs[prec]["sustained_clock_detail"] = pmc_sustained_clock(prec)

@@ -13,7 +13,7 @@ torch.manual_seed(6); m = boost(m).to(dev)
 R, S = 65536, 192
 ro = torch.zeros(R, 3, device=dev); rd = torch.randn(R, 3, device=dev) * 0.3; z = torch.sort(torch.rand(R, S, device=dev) * 0.6 + 0.2, dim=-1)[0]
 expr = torch.randn(76, device=dev); lat = torch.randn(32, device=dev) * 0.1
-for prec in ("f32", "bf16x3"):
+for prec in ("f32", "bf16x3", "f16x3", "f16x2"):
     nerf.set_mlp_precision(prec)
     for _ in range(2): m.hip_forward(ro, rd, z, rd, expr, lat, 0.2, 0.8, False)
     torch.cuda.synchronize(); t = time.perf_counter()
@@ -38,7 +38,7 @@ def frame():
     with torch.no_grad():
         return nerf.run_one_iter_of_nerf(512, 512, INTRINSICS, mc, m, ro, rd, opt, mode="validation", encode_position_fn=ex,
                                          encode_direction_fn=ed, expressions=expr, background_prior=bg, latent_code=lat)
-for prec in ("f32", "bf16x3"):
+for prec in ("f32", "bf16x3", "f16x3", "f16x2"):
     nerf.set_mlp_precision(prec)
     for _ in range(2): frame()
     torch.cuda.synchronize(); t = time.perf_counter()

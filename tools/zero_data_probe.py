@@ -26,7 +26,8 @@ for rep in range(2):
         cond = ops.paper_condition(hw.get(), expr, lat, 0.2, 0.8)
         for name, fn in (("f32", lambda: ops.paper_mlp_fwd(hw.get(), cond, ro_u, rd_u, z)),
                          ("bf16x3", lambda: ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, ro_u, rd_u, z)),
-                         ("f16x3", lambda: ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro_u, rd_u, z))):
+                         ("f16x3", lambda: ops.paper_mlp_fwd_f16(hw.get_f16(), cond, ro_u, rd_u, z)),
+                         ("f16x2", lambda: ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, ro_u, rd_u, z))):
             fn(); fn(); torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
