@@ -223,3 +223,21 @@ def test_tiny_gradient_fixture():
     for k, v in tp.items():
         want = torch.from_numpy(g["grad:" + k])
         assert float((v.grad - want).norm() / (want.norm() + 1e-30)) < 1e-5, k
+
+
+def test_split_emulation_model_is_sane():
+    """oracle/split_emulation.py (the numerical model behind profiles/r05_split_products.md): the operand columns that go through the
+    MFMAs are the ones the kernels stream (the expression / latent / near / far columns are folded into biases in f32), and on a few
+    points the modelled arithmetics order as measured: x2 (22-bit weights, 11-bit activations) within 1e-3 of the exact MLP, x1 not better."""
+    from oracle import split_emulation as S
+    assert int(S.Emu.stream_mask("layers_xyz.0", 171).sum()) == 63 and int(S.Emu.stream_mask("layers_xyz.3", 427).sum()) == 63 + 256
+    assert int(S.Emu.stream_mask("layers_dir.0", 280).sum()) == 256 + 8 and int(S.Emu.stream_mask("fc_feat", 256).sum()) == 256
+    c = C.build_case("soft_eval_det_64_128")
+    pc = {k: v.double() for k, v in c["p_coarse"].items()}
+    x = O.encode_points(c["ro"].double()[:6], c["rd"].double()[:6], torch.linspace(0.2, 0.8, 9).expand(6, 9).double(), O.NEAR, O.FAR)
+    ref = O.paper_mlp(pc, x, c["expr"].double(), c["latent"].double())
+    err = {m: (S.Emu(pc, m).forward(x, c["expr"].double(), c["latent"].double()) - ref).abs().amax(0) for m in ("x2", "x1")}
+    scale = ref.abs().amax(0)
+    assert torch.all(err["x2"] <= 1e-3 * scale + 2e-4), err["x2"]
+    assert float(err["x1"].sum()) >= 0.5 * float(err["x2"].sum())
+    assert S.layer_scale(torch.tensor([0.06, -0.03])) == 2.0 ** 18              # 0.06 = 0.96 * 2^-4 -> scaled maximum in [2^13, 2^14)
