@@ -52,8 +52,9 @@ def quant_rows_feedback(ws):
 class Emu:
     """One network (parameter dict p, float64 on the device) in one arithmetic."""
 
-    def __init__(self, p, mode):
-        self.p, self.mode = p, mode
+    def __init__(self, p, mode, w22=()):
+        """mode: x2 | x1 | x1c | x1e | x1ec; w22: layer names that keep 22-bit weights whatever the mode (mixed arithmetics)."""
+        self.p, self.mode, self.w22 = p, mode, set(w22)
         self.corr = {}
         two_w = mode == "x2"
         fb = "e" in mode[2:]
@@ -69,7 +70,9 @@ class Emu:
             else:
                 s = layer_scale(ws_all)
             hi = (quant_rows_feedback(ws_all * s) if fb else Q(ws_all * s))
-            wq = hi + (Q(ws_all * s - hi) if two_w else 0.0)
+            if name in self.w22:
+                hi = Q(ws_all * s)
+            wq = hi + (Q(ws_all * s - hi) if (two_w or name in self.w22) else 0.0)
             full = w.clone()
             full[:, stream] = wq / s
             self.wq[name] = full
@@ -150,6 +153,41 @@ def render(c, dev, emus=None, rays=None, chunk=4096, capture=None):
     return torch.cat(parts, dim=0), pc, pf, expr, lat
 
 
+MIXES = {  # name: (layers that keep W_lo, MFMAs per 32 points of the kernel that would implement it)
+    "feat+alpha": (("fc_feat", "fc_alpha"), 1152),
+    "h5+feat+alpha": (("layers_xyz.5", "fc_feat", "fc_alpha"), 1280),
+    "h3..5+feat+alpha": (("layers_xyz.3", "layers_xyz.4", "layers_xyz.5", "fc_feat", "fc_alpha"), 1568),
+    "trunk+feat+alpha (dir layers x1)": (tuple(f"layers_xyz.{i}" for i in range(6)) + ("fc_feat", "fc_alpha"), 1856),
+}
+
+
+def main_mixes():
+    """Mixed arithmetics: 11-bit activations everywhere, 22-bit weights only on the named layers, 11-bit (+ bias correction) on the rest."""
+    dev = torch.device("cuda:0")
+    H = W = 512
+    psnr = lambda a, b: -10.0 * float(torch.log10(torch.mean((a - b) ** 2)))
+    for family, case in (("x1000 head", "eval_det_64_128"), ("x40 head", "soft_eval_det_64_128")):
+        c = C.build_case(case)
+        ro, rd = O.ray_bundle(H, W, O.INTRINSICS, O.frame_pose(c["frame"]))
+        bg, tgt = O.synthetic_image(H, W, 7).reshape(-1, 3), O.synthetic_image(H, W, 11).reshape(-1, 3).to(dev).double()
+        rays = (ro.reshape(-1, 3), rd.reshape(-1, 3), bg)
+        ref, pc, pf, expr, lat = render(c, dev, None, rays)
+        cap = {}
+        render(c, dev, None, tuple(t[::1024] for t in rays), capture=cap)
+        for name, (w22, n_mfma) in MIXES.items():
+            for mode in ("x1", "x1c"):
+                emus = {"c": Emu(pc, mode, w22), "f": Emu(pf, mode, w22)}
+                if mode == "x1c":
+                    for which, p in (("c", pc), ("f", pf)):
+                        means = {}
+                        with torch.no_grad():
+                            Emu(p, "x2").forward(torch.cat(cap[which], 0)[::8], expr, lat, means=means)
+                        emus[which].calibrate({k: v for k, v in means.items() if k not in w22})
+                img = render(c, dev, emus, rays)[0]
+                print(f"[{family}] W22 on {name} ({n_mfma} MFMAs), rest {mode}: |dPSNR| = {abs(psnr(img, tgt) - psnr(ref, tgt)):.2e} dB, "
+                      f"self-PSNR {psnr(img, ref):.1f} dB", flush=True)
+
+
 def main():
     dev = torch.device("cuda:0")
     H = W = 512
@@ -178,4 +216,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    main_mixes() if sys.argv[1:] == ["mixes"] else main()
