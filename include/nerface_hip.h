@@ -123,7 +123,7 @@ int nf_paper_mlp_fwd_f16(const void* packed_f16, const float* cond, const float*
                          const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
 /* "f16x2" (round 5, csrc/nf_mlp_f16x2.hip): the same call on the same packed image with TWO fp16 products per weight -- activations enter
  * with their 11-bit `hi` half only, weights keep 22 bits: W_hi x_hi + W_lo x_hi, a third fewer MFMAs.  Inference only.  Whole 512 x 512
- * frames stay within north_star's 1e-4 dB of the reference (measured 5e-6 .. 1e-5 dB, self-PSNR 91 .. 115 dB); per-point outputs carry
+ * frames stay within north_star's 1e-4 dB of the reference (measured 2e-6 .. 5.6e-5 dB over 21 frames, self-PSNR 60 .. 115 dB); per-point outputs carry
  * fp16's 2^-12 relative rounding of the activations (profiles/r05_split_products.md).  Range and range guard as nf_paper_mlp_fwd_f16. */
 int nf_paper_mlp_fwd_f16x2(const void* packed_f16, const float* cond, const float* ro, const float* rd, const float* rd_view,
                            const float* z, int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
