@@ -103,6 +103,12 @@ def _main(argv=None):
                     help="f32 (default) = the reference's arithmetic, exact-f32 MFMA; f16x3 = split-fp16 kernels, fp32-class results, "
                          "2.7x faster; bf16x3 = split-bf16, 2.9x; f16x2 = two fp16 products per weight, 3.5x -- the last two within the "
                          "1e-4 dB PSNR gate, not fp32-class per point (tests/test_gpu_bf16.py, tests/test_gpu_f16x2.py)")
+    ap.add_argument("--verify-gate", type=int, default=0, metavar="K",
+                    help="with a --precision other than f32: every K-th frame of this rank is ALSO rendered on the exact-f32 kernels with the "
+                         "same random draws, and the launcher reports |PSNR(frame, test image) - PSNR(f32 frame, test image)| and the "
+                         "self-PSNR -- north_star's 1e-4 dB gate measured on YOUR sequence (it varies by an order of magnitude from frame to "
+                         "frame and scene to scene: profiles/r05_split_products.md); 0 = off")
+    ap.add_argument("--gate-strict", action="store_true", help="with --verify-gate: raise if a verified frame misses the 1e-4 dB gate")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default=os.environ.get("NERFACE_DIST_BACKEND", "nccl"))
     ap.add_argument("--as-shipped", action="store_true",
                     help="render exactly what eval_transformed_rays.py renders as shipped (EV:420-446): ablate = 'view_dir' -- pose and "
@@ -165,6 +171,7 @@ def _main(argv=None):
     # "avg time per image" (the reference's metric, EV:471-473) from HIP events around each frame's kernels: nothing in the loop
     # waits for the GPU (PNG output and post-processing are asynchronous), so host clocks would time the launches, not the render
     marks = []
+    gate_rows = []                                                        # (frame, |dPSNR| vs the f32 frame, self-PSNR): device scalars, read at the end
     t_start = time.time()
     for i in mine:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -180,11 +187,29 @@ def _main(argv=None):
         else:
             row = int(idx_map[i, 1]) if idx_map is not None and i < len(idx_map) else 0
             latent = latent_codes[min(max(row, 0), latent_codes.shape[0] - 1)]
+            verify = args.verify_gate > 0 and args.precision != "f32" and len(marks) % args.verify_gate == 0
             with torch.no_grad():
                 ro, rd = nerf.get_ray_bundle(H, W, intrinsics, poses[i, :3, :4].to(dev))
-                out = nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
-                                                encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
-                                                expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
+
+                def render():
+                    if verify:
+                        torch.manual_seed(977 + i)                            # the same draws in both arithmetics
+                    return nerf.run_one_iter_of_nerf(H, W, intrinsics, model_c, model_f, ro, rd, cfg, mode="validation",
+                                                     encode_position_fn=enc_xyz, encode_direction_fn=enc_dir,
+                                                     expressions=expressions[i].to(dev), background_prior=background, latent_code=latent)
+                out = render()
+                if verify:
+                    nerf.set_mlp_precision("f32")
+                    try:
+                        exact = render()
+                    finally:
+                        nerf.set_mlp_precision(args.precision)
+                    k = 3 if out[3] is not None else 0
+                    gt = images[i].to(dev)[..., :3].reshape(H, W, 3).double()
+                    mse = lambda a, b: torch.mean((a.double() - b) ** 2)
+                    psnr = lambda a, b: -10.0 * torch.log10(mse(a, b))
+                    gate_rows.append((i, (psnr(out[k][..., :3], gt) - psnr(exact[k][..., :3], gt)).abs(),
+                                      psnr(out[k][..., :3], exact[k][..., :3].double())))
         rgb = out[3] if out[3] is not None else out[0]
         # clamp / quantise (and the normal map) on the device: only uint8 crosses PCIe
         want_n = (args.save_normals or shipped is not None) and out[4] is not None            # EV:469-471 always writes normals/
@@ -210,6 +235,19 @@ def _main(argv=None):
     main.last_stats = {"frames": len(times), "gpu_s_per_frame": sum(times) / len(times) if times else None,
                        "gpu_s_total": sum(times), "wall_s": t_end - t_start, "wall_s_until_gpu_idle": t_gpu_done - t_start,
                        "frames_s": len(times) / (t_end - t_start) if times else None}
+    if gate_rows:
+        rows = [(f, float(d), float(sp)) for f, d, sp in gate_rows]
+        worst = max(rows, key=lambda r: r[1])
+        main.last_stats["gate"] = {"frames": len(rows), "worst_abs_dpsnr_db": worst[1], "worst_frame": worst[0],
+                                   "min_self_psnr_db": min(r[2] for r in rows), "precision": args.precision}
+        print(f"[rank {rank}] gate check of --precision {args.precision} on {len(rows)} frame(s) against the exact-f32 kernels: worst |dPSNR| "
+              f"{worst[1]:.2e} dB (frame {worst[0]}; north_star's gate: 1e-4), lowest self-PSNR {min(r[2] for r in rows):.1f} dB")
+        if worst[1] > 1e-4:
+            msg = (f"--precision {args.precision}: frame {worst[0]} differs from the exact-f32 render by {worst[1]:.2e} dB of PSNR against its "
+                   f"test image (gate 1e-4) -- render this sequence with f16x3 or f32")
+            if args.gate_strict:
+                raise RuntimeError(msg)
+            print("WARNING: " + msg)
     if times:
         print(f"[rank {rank}] rendered {len(times)} of {n} frames, avg time per image: {sum(times) / len(times):.3f} s "
               f"(GPU time per frame; wall {t_end - t_start:.1f} s including PNG output)")

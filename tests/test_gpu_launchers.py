@@ -88,6 +88,12 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out4, "--precision", "f16x2"]) == [0, 1, 2]
     x2 = np.asarray(Image.open(os.path.join(out4, "0001.png")))
     assert x2.shape == a.shape and x2.std() > 0
+    out5 = os.path.join(base, "render_x2_verified")  # --verify-gate: every frame also on the exact-f32 kernels, same draws; the gate is REPORTED
+    assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out5, "--precision", "f16x2", "--verify-gate", "1"]) == [0, 1, 2]
+    gate = eval_sharded.main.last_stats["gate"]
+    print("launcher gate check (32 x 32 frames: 1024 rays, a noisy estimate of the metric):", gate)
+    assert gate["frames"] == 3 and gate["precision"] == "f16x2" and np.isfinite(gate["worst_abs_dpsnr_db"]) and gate["min_self_psnr_db"] > 40.0
+    assert nerf.get_mlp_precision() == "f32"           # the launcher leaves the process-global switch as it found it
     assert os.path.exists(os.path.join(out, "disparity", "0002.png"))
 
 
