@@ -1053,6 +1053,8 @@ def main():
     from nerf import ops
     nerf.set_mlp_precision(args.precision)
 
+    if args.mode == "train" and args.precision in ops.INFERENCE_ONLY_PRECISIONS:
+        raise SystemExit(f"--mode train: {args.precision} is an inference arithmetic (train with f32, f16x3 or bf16x3)")
     if args.family != "paper" and args.mode != "train":
         raise SystemExit("--family lcode is a --mode train option (the eval line is BASELINE.json's paper-model metric)")
     model_c, model_f = synth_params(0, dev, args.family), synth_params(1, dev, args.family)
