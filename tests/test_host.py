@@ -203,7 +203,9 @@ def test_bench_compact_line_fits_the_driver_record():
     line["eager_rocm"].update(kind="reference", port={"value": 255026.83364130167})
     import copy
     line["split_f16x2"] = copy.deepcopy(line["split_f16"])                 # round 5: the fourth arithmetic
-    line["split_f16x2"]["whole_frame_vs_exact_f32"] = {"abs_dpsnr_db": 3.5123456789012345e-05, "self_psnr_db": 67.41234567890123}
+    for k in ("split_f16x2", "split_f16", "split_bf16"):
+        line[k]["whole_frame_vs_exact_f32"] = {"abs_dpsnr_db": 3.5123456789012345e-05, "self_psnr_db": 67.41234567890123, "frames_checked": 4,
+                                              "worst_abs_dpsnr_db": 5.6123456789012345e-05}
     line["cpu_baseline"]["parity_on_sample"]["f16x2"] = dict(line["cpu_baseline"]["parity_on_sample"]["f16x3"])
     line["tiny"]["cpu_baseline"].update(kind="reference")
     line["summary"] = B.summary_of(line)
