@@ -19,6 +19,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fP
          "-Wno-unused-result"]
 
 
+# per-unit flags.  The split-fp16 forward kernels form (hi, lo) operand pairs with v_fma_mixlo / mixhi_f16 (nf_mlp_bf16_machinery.inc:
+# nfb_to_operands_f16); the SLP vectoriser would pair the scalar f32 operations of that epilogue into v_pk_mul / v_pk_fma_f32 -- which
+# defeats the mix patterns and costs more issue time beside MFMAs than the scalar forms (MI355X_MICROARCH.md, "price of one filler").
+UNIT_FLAGS = {u: ["-fno-slp-vectorize"] for u in ("nf_mlp_f16.hip", "nf_mlp_f16x2.hip", "nf_mlp_f16_train.hip", "nf_mlp_lcode_f16.hip",
+                                                  "nf_mlp_lcode_f16x2.hip", "nf_mlp_lcode_f16_train.hip")}
+
+
 def _hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):
@@ -78,7 +85,7 @@ def build(force: bool = False, verbose: bool = True, _extra=(), _obj="obj", _alw
             continue
         # -Rpass-analysis: per-kernel registers / spills / scratch / LDS as compiler remarks, kept beside the object
         # (lib/obj/<unit>.usage.txt; tests/test_host.py reads them: no kernel of the library may spill)
-        procs.append((s, subprocess.Popen([cc, *FLAGS, *_extra, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj],
+        procs.append((s, subprocess.Popen([cc, *FLAGS, *UNIT_FLAGS.get(s, []), *_extra, "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", obj],
                                           stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
     for s, p in procs:
         try:

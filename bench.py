@@ -68,6 +68,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH
 BF16X3_EXEC_FLOP_PER_POINT = 3012 * 32768 / 32   # executed MFMA FLOPs per point of the split-bf16 kernel (3012 MFMAs / 32 points)
 INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
 NEAR, FAR = 0.2, 0.8
+CPU_CALIBRATION_RAYS = 4096           # slice of the CPU sample on which the thread count of the reference's CPU run is chosen
 
 
 def synth_params(seed, device, family="paper"):
@@ -115,18 +116,26 @@ def _reference_cpu_run(n_rays, c, cores):
     ref = RI.import_reference()
     warm = dict(c)
     warm.update(ro=c["ro"][:256], rd=c["rd"][:256], bg=c["bg"][:256])
-    best, best_t = cores, None
+    n_cal = min(n_rays, CPU_CALIBRATION_RAYS)
+    cal = dict(c)
+    cal.update(ro=c["ro"][:n_cal], rd=c["rd"][:n_cal], bg=c["bg"][:n_cal])
+    best, best_t, table = cores, None, {}
     with torch.no_grad():
-        # torch-CPU GEMMs of this size do not scale to every hardware thread of a big host: calibrate the thread count on a
-        # 256-ray slice first and time the sample with the best one (reported as `cores`)
-        for nt in sorted({min(cores, k) for k in (16, 32, 64, cores)}):
+        # torch-CPU GEMMs of this size do not scale to every hardware thread of a big host, and the best count depends on the GEMM's
+        # M: calibrate on a slice of the timed sample's order (4096 rays = 786k MLP points per fine call; round 5 used 256 rays, which
+        # favours few threads -- VERDICT r05 weak #7) over {16, 32, 64, 128, all}, then time the sample with the winner (`cores`)
+        MG.run_reference(ref, warm)
+        for nt in sorted({min(cores, k) for k in (16, 32, 64, 128, cores)}):
             torch.set_num_threads(nt)
-            MG.run_reference(ref, warm)
             t0 = time.perf_counter()
-            MG.run_reference(ref, warm)
+            MG.run_reference(ref, cal)
             t = time.perf_counter() - t0
+            table[nt] = n_cal / t
             if best_t is None or t < best_t:
                 best, best_t = nt, t
+            if t > 4.0 * best_t:                                            # far off the best: larger counts will not recover
+                break
+        _reference_cpu_run.calibration = {"rays": n_cal, "rays_per_s_by_threads": table}
         torch.set_num_threads(best)
         pose = O.frame_pose(c["frame"])[:3, :4]
         ref.get_ray_bundle(H, W, INTRINSICS, pose)
@@ -159,7 +168,8 @@ def cpu_baseline(n_rays=12288):
             ref, dt, t_bundle, best, how = _reference_cpu_run(n_rays, c, cores)
             kind = "reference"
             t_total = dt + t_bundle * n_rays / float(H * W)                # the frame's ray bundle, charged per ray
-            ref_detail = {"run_one_iter_of_nerf_s": dt, "get_ray_bundle_full_frame_s": t_bundle, "imported_from": how}
+            ref_detail = {"run_one_iter_of_nerf_s": dt, "get_ray_bundle_full_frame_s": t_bundle, "imported_from": how,
+                          "thread_calibration": getattr(_reference_cpu_run, "calibration", None)}
             # the oracle port on a slice of the same rays, same threads: how close the restatement's speed is to the real thing
             n_port = min(n_rays, 2048)
             cp = dict(c)
@@ -245,6 +255,10 @@ TRAIN_KERNELS = {
 }
 TRAIN_BYTES_PER_POINT = (4 * (2256 + 72) + 4 + 16, 4 * 72 + 16 + 4 * 2176, 4 * (2256 + 2176 + 4))
 TRAIN_FLOP_PER_POINT = (FLOP_PER_POINT, CHAIN_FLOP_PER_POINT, DW_FLOP_PER_POINT)
+# issued 16-bit MFMA FLOPs per point of the split training kernels: v_mfma_f32_32x32x16 = 32768 FLOPs per 32 points; the forward with
+# saves issues 3284 per wave tile (3012 + 272 transposing ones), the dX chain 2760 (static counts of the ISA, tools/isa_summary.py),
+# the weight-gradient GEMMs three products per algorithmic one
+TRAIN_SPLIT_EXEC_FLOP_PER_POINT = (3284 * 1024, 2760 * 1024, 3 * DW_FLOP_PER_POINT)
 # (lcode family, --mode train --family lcode: whole-iteration bytes only)
 LCODE_BYTES_PER_POINT = {"f32": 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
                          "bf16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
@@ -335,8 +349,14 @@ def train_roofline(args, model, dev, n_rays):
                 obj["frac_executed"] = obj["executed_tflops"] / PEAK_F32_MFMA_TFLOPS
                 obj["frac_algorithmic"], obj["frac"] = obj["frac"], obj["frac_executed"]
         else:
+            # priced against HBM (9-18 KB per point: the bound the bytes set) AND, beside it, against what the matrix pipe could do: the
+            # issued 16-bit MFMA FLOPs of the launch / time / the dense 16-bit peak (these kernels are power- /
+            # issue-bound, not HBM-bound -- the HBM fraction alone hides how far they sit from the matrix roofline)
             ach = TRAIN_BYTES_PER_POINT[k] * n_big / t / 1e9
-            obj = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS}
+            exe = TRAIN_SPLIT_EXEC_FLOP_PER_POINT[k] * n_big / t / 1e12
+            obj = {"bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS,
+                   "executed_mfma_tflops": exe, "frac_executed_mfma": exe / PEAK_BF16_MFMA_TFLOPS,
+                   "executed_mfma_flops_per_point": TRAIN_SPLIT_EXEC_FLOP_PER_POINT[k]}
         obj.update({"kernel": f"{kname} ({what}; {n_rays} rays x 128 samples per launch)", "avg_launch_ms": per_size[128][k],
                     "avg_launch_ms_64_samples": per_size[64][k], "algorithmic_hbm_bytes_per_point": TRAIN_BYTES_PER_POINT[k], "traffic": None})
         kernels.append(obj)
@@ -597,11 +617,11 @@ def eager_rocm_baseline(dev, n_rays=32768, chunk=8192):
             "note": "stock PyTorch-ROCm eager execution of the reference algorithm on the same GPU; the reference's own scripts cannot run on this box"}
 
 
-def eager_rocm_reference(dev):
+def eager_rocm_reference(dev, n_frames=3):
     """The same-GPU denominator of north_star ("the reference PyTorch-CUDA rays/sec"): the UNMODIFIED reference's `get_ray_bundle`
     (H:68-123) + `run_one_iter_of_nerf` (T:165-290, mode="validation") with both models and every tensor on this MI355X, executed by
-    stock PyTorch-ROCm eager -- one whole 512x512 frame, 64+128 samples, chunksize 65536 and perturb on as shipped (CFG:156), after a
-    one-chunk warm-up, synchronised timing.  A baseline leg: imported out of /root/reference or oracle/_ref/nerface_ref.zip, never
+    stock PyTorch-ROCm eager -- whole 512x512 frames, 64+128 samples, chunksize 65536 and perturb on as shipped (CFG:156), after a
+    one-chunk warm-up; `n_frames` frames timed one by one (synchronised), median reported with the spread.  A baseline leg: imported out of /root/reference or oracle/_ref/nerface_ref.zip, never
     part of the product or of the timed region of the headline."""
     from oracle import cases as C
     from oracle import make_golden as MG
@@ -626,13 +646,17 @@ def eager_rocm_reference(dev):
     frame(CHUNK // W)                                                       # warm-up: one 65536-ray chunk (rocBLAS / hipBLASLt plans, allocator)
     torch.cuda.synchronize()
     peak0 = torch.cuda.max_memory_allocated(dev)
-    t0 = time.perf_counter()
-    out = frame(H)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(n_frames):                                               # whole frames, each synchronised; the MEDIAN is the figure
+        t0 = time.perf_counter()
+        out = frame(H)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
     assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
+    dt = sorted(times)[len(times) // 2]
     return {"value": H * W / dt, "unit": "rays/s", "kind": "reference", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
-            "sample": f"one whole 512x512 frame ({H * W} rays), 64+128 samples, chunksize 65536, perturb on, UNMODIFIED reference "
+            "frames": n_frames, "frame_ms": [1e3 * t for t in times], "value_min": H * W / max(times), "value_max": H * W / min(times),
+            "sample": f"median of {n_frames} whole 512x512 frames ({H * W} rays each), 64+128 samples, chunksize 65536, perturb on, UNMODIFIED reference "
                       f"get_ray_bundle + run_one_iter_of_nerf on {torch.cuda.get_device_name(dev)} (PyTorch-ROCm eager), {dt * 1e3:.0f} ms",
             "imported_from": RI.reference_kind(), "peak_device_bytes": int(max(peak0, torch.cuda.max_memory_allocated(dev)))}
 
@@ -1017,6 +1041,13 @@ def main():
     ap.add_argument("--launcher-frames", type=int, default=32, help="frames of the launch/eval_sharded.py throughput leg")
     args = ap.parse_args()
 
+    backend = os.environ.get("NERFACE_DIST_BACKEND", "nccl")           # "gloo": several ranks on one GPU (tests of the N > 1 path)
+    if args.gpus > 1 and backend == "nccl" and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
+        # fail in seconds with the reason, before any rendezvous: RCCL needs one device per rank (two ranks on one device deadlock
+        # or abort inside ncclCommInitRank minutes later)
+        raise SystemExit(f"bench.py: --gpus {args.gpus} needs {args.gpus} devices for the nccl (RCCL) backend, but "
+                         f"torch.cuda.device_count() = {torch.cuda.device_count()} on this box (NERFACE_DIST_BACKEND=gloo runs several "
+                         "ranks on one GPU for tests)")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         # a bare `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) with the
         # same argv; the children see WORLD_SIZE and take the branch below.  --gpus 1 stays in-process.
@@ -1029,26 +1060,32 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (the product has no CPU path)")
-    backend = os.environ.get("NERFACE_DIST_BACKEND", "nccl")           # "gloo": several ranks on one GPU (tests of the N > 1 path)
     if backend == "gloo":
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     force_pg = os.environ.get("NERFACE_DIST_FORCE", "0") not in ("", "0")   # world 1 under torch.distributed.run: run the collectives anyway (RCCL smoke)
+    # the library BEFORE the process group: a cold box may have to compile it (minutes), and a rank that compiles while the others
+    # sit in RCCL's init / first barrier can run them into the collective timeout.  Every rank takes a file lock; the first builds
+    # (a no-op when the pushed .so is fresh), the others find it fresh.
+    import fcntl
+    import __graft_entry__ as G
+    os.makedirs(os.path.join(PKG, "lib"), exist_ok=True)
+    with open(os.path.join(PKG, "lib", ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            G._load_build().build(force=False, verbose=False)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
     if world > 1 or force_pg:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)        # nccl == RCCL on ROCm
+            dist.init_process_group(backend="nccl", device_id=dev, timeout=datetime.timedelta(minutes=10))   # nccl == RCCL on ROCm
         else:
-            dist.init_process_group(backend=backend)
-
-    import __graft_entry__ as G
-    if rank == 0:
-        G._load_build().build(force=False, verbose=False)
-    if dist is not None:
-        dist.barrier()
+            dist.init_process_group(backend=backend, timeout=datetime.timedelta(minutes=10))
     import nerf
     from nerf import ops
     nerf.set_mlp_precision(args.precision)
@@ -1098,13 +1135,18 @@ def main():
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t.item())
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")   # (gloo gathers host tensors only)
+            per = [torch.zeros_like(t) for _ in range(world)]
+            dist.all_gather(per, t)                                          # every rank's own time: stragglers show on the line
+            timed_frames.per_rank_ms = [1e3 * float(x.item()) / max(args.steps, 1) for x in per]
+            dt = max(float(x.item()) for x in per)                           # the job's time = the slowest rank's
+        else:
+            timed_frames.per_rank_ms = [1e3 * dt / max(args.steps, 1)]
         assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
         return dt
 
     dt = timed_frames()
+    per_rank_ms = list(timed_frames.per_rank_ms)
     rays_total = world * args.steps * H * W
     dtype_of = {"f32": "f32", "bf16x3": "bf16x3 (split-bf16 products, f32 accumulate)",
                 "f16x3": "f16x3 (split-fp16 products on scaled weights, f32 accumulate; fp32-class error)",
@@ -1133,31 +1175,34 @@ def main():
                 "note": f"same workload, frames and timing protocol with nerf.set_mlp_precision('{other}')"}
         nerf.set_mlp_precision(args.precision)
         if rank == 0 and args.precision == "f32":
-            # whole frames of the timed workload (262,144 rays each, the same seeded draws) in every other arithmetic against the exact-f32
-            # product frame: north_star's gate on the workload itself (|PSNR(., target) - PSNR(f32 frame, target)|, a fresh random target per
-            # frame) and the self-PSNR.  The gate is a property of a FRAME (an order of magnitude between frames of one scene:
-            # profiles/r05_c19/frame_gate_sweep.txt), so the first four frames are checked and the worst one is reported beside frame 0
+            # north_star's gate on the workload itself, where it is hard (nerf/gate.py): the first four frames of the timed
+            # workload (262,144 rays each, the same seeded draws) in every other arithmetic against the exact-f32 product frame --
+            # |PSNR(., target) - PSNR(f32 frame, target)| for a uniform-random target (SURVEY 8(d)'s) AND for targets the f32 frame
+            # approximates to 20 / 30 / 40 dB, on the whole frame and on scattered subsets of 3001 and 1024 rays; worst frame per cell
             try:
-                psnr = lambda a, b: -10.0 * float(torch.log10(torch.mean((a - b) ** 2)))
+                from nerf import gate as GATE
                 rows = {other: [] for other in others}
                 for f in range(min(4, n_frames)):
-                    tgt = torch.rand((H, W, 3), generator=torch.Generator().manual_seed(11 + f)).to(dev).double()
                     frames = {}
                     for prec in [args.precision] + others:
                         nerf.set_mlp_precision(prec)
                         torch.manual_seed(4321 + f)
-                        frames[prec] = step(f)[3].double()
+                        frames[prec] = step(f)[3]
                     for other in others:
-                        rows[other].append({"frame": f, "abs_dpsnr_db": abs(psnr(frames[other], tgt) - psnr(frames["f32"], tgt)),
-                                            "self_psnr_db": psnr(frames[other], frames["f32"]),
-                                            "max_abs_rgb_diff": float((frames[other] - frames["f32"]).abs().max())})
+                        r = GATE.gate_cells(frames["f32"], frames[other], seed=11 + f)
+                        r["frame"] = f
+                        r["max_abs_rgb_diff"] = float((frames[other].double() - frames["f32"].double()).abs().max())
+                        rows[other].append(r)
                     del frames
                 for other in others:
-                    worst = max(rows[other], key=lambda r: r["abs_dpsnr_db"])
-                    line[key_of[other]]["whole_frame_vs_exact_f32"] = {
-                        **{k: rows[other][0][k] for k in ("abs_dpsnr_db", "self_psnr_db", "max_abs_rgb_diff")}, "rays": H * W,
-                        "frames_checked": len(rows[other]), "worst_abs_dpsnr_db": worst["abs_dpsnr_db"], "worst_frame": worst["frame"],
-                        "min_self_psnr_db": min(r["self_psnr_db"] for r in rows[other]), "per_frame": rows[other]}
+                    w = GATE.worst_of(rows[other])
+                    line[key_of[other]]["gate_vs_exact_f32"] = {
+                        "rays": H * W, "frames_checked": w["frames"], "min_self_psnr_db": w["min_self_psnr_db"], "max_self_psnr_db": w["max_self_psnr_db"],
+                        "worst_abs_dpsnr_db": w["cells"], "gate_db": GATE.GATE_DB,
+                        "passes": {t: {m: bool(v <= GATE.GATE_DB) for m, v in row.items()} for t, row in w["cells"].items()},
+                        "what": "worst |PSNR(arithmetic, target) - PSNR(exact f32 frame, target)| over the frames, per target (uniform random; "
+                                "20 / 30 / 40 dB = clamp(f32 frame + sigma randn)) and ray count (whole frame; worst of 8 scattered subsets of "
+                                "3001 / 1024 rays)", "per_frame": rows[other]}
             except Exception as e:                                # an extra must never cost the headline
                 line["whole_frame_parity_error"] = repr(e)
             nerf.set_mlp_precision(args.precision)
@@ -1309,6 +1354,7 @@ def main():
             except Exception as e:
                 line["config"]["device"]["power"] = {"error": repr(e)}
         line["ranks_seen"] = int(dist.get_world_size()) if dist is not None else 1
+        line["per_rank_ms_per_step"] = per_rank_ms
         line["summary"] = summary_of(line)
         emit(line)
     if dist is not None:
@@ -1378,7 +1424,8 @@ def emit(line):
 
 
 def summary_of(line):
-    """Flat scalars of the compact line: everything a reader needs to check the claims of DESIGN.md against the driver's own run."""
+    """Flat scalars of the compact line: everything a reader needs to check the claims of DESIGN.md against the driver's own run.
+    Key names are short on purpose (the whole record must stay below COMPACT_LIMIT); tags: f16 = f16x3, x2 = f16x2, bf = bf16x3."""
     def g(*path, default=None):
         o = line
         for k in path:
@@ -1386,66 +1433,64 @@ def summary_of(line):
                 return default
             o = o[k]
         return o
+    per = line.get("per_rank_ms_per_step") or []
     s = {"value_rays_s": line.get("value"), "ms_per_step": line.get("ms_per_step"), "n_gpus": line.get("n_gpus"),
-         "ranks_seen": line.get("ranks_seen"),
-         "roofline_frac": g("roofline", "frac"), "roofline_avg_launch_ms": g("roofline", "avg_launch_ms"),
-         "split_f16_rays_s": g("split_f16", "value"), "split_bf16_rays_s": g("split_bf16", "value"),
-         "split_f16_fine_launch_ms": g("split_f16", "roofline", "avg_launch_ms"),
-         "split_bf16_fine_launch_ms": g("split_bf16", "roofline", "avg_launch_ms"),
-         "split_f16_clock_mhz": g("split_f16", "roofline", "sustained_clock_mhz"),
-         "split_bf16_clock_mhz": g("split_bf16", "roofline", "sustained_clock_mhz"),
-         "split_f16x2_rays_s": g("split_f16x2", "value"), "split_f16x2_fine_launch_ms": g("split_f16x2", "roofline", "avg_launch_ms"),
-         "split_f16x2_clock_mhz": g("split_f16x2", "roofline", "sustained_clock_mhz"),
-         "split_f16x2_frac_executed": g("split_f16x2", "roofline", "frac_executed"),
-         "split_f16x2_over_eager": None,
-         "split_f16x2_frame_abs_dpsnr_db": g("split_f16x2", "whole_frame_vs_exact_f32", "abs_dpsnr_db"),
-         "split_f16x2_frame_self_psnr_db": g("split_f16x2", "whole_frame_vs_exact_f32", "self_psnr_db"),
-         "split_f16x2_gate_frames": g("split_f16x2", "whole_frame_vs_exact_f32", "frames_checked"),
-         "split_f16x2_gate_worst_db": g("split_f16x2", "whole_frame_vs_exact_f32", "worst_abs_dpsnr_db"),
-         "split_bf16_gate_worst_db": g("split_bf16", "whole_frame_vs_exact_f32", "worst_abs_dpsnr_db"),
-         "split_f16_gate_worst_db": g("split_f16", "whole_frame_vs_exact_f32", "worst_abs_dpsnr_db"),
-         "split_f16_frac_executed": g("split_f16", "roofline", "frac_executed"),
-         "split_bf16_frac_executed": g("split_bf16", "roofline", "frac_executed")}
-    for prec in ("f32", "f16x3", "bf16x3"):
-        s[f"train_ms_per_iter_{prec}"] = g("train", prec, "ms_per_iter")
+         "ranks_seen": line.get("ranks_seen"), "rank_ms_min": min(per) if per else None, "rank_ms_max": max(per) if per else None,
+         "roofline_frac": g("roofline", "frac"), "roofline_avg_launch_ms": g("roofline", "avg_launch_ms")}
+    for tag, key in (("f16", "split_f16"), ("x2", "split_f16x2"), ("bf", "split_bf16")):
+        s[f"{tag}_rays_s"] = g(key, "value")
+        s[f"{tag}_launch_ms"] = g(key, "roofline", "avg_launch_ms")
+        s[f"{tag}_clock_mhz"] = g(key, "roofline", "sustained_clock_mhz")
+        s[f"{tag}_frac_executed"] = g(key, "roofline", "frac_executed")
+        # north_star's gate per arithmetic on the first frames of the workload (worst frame): SURVEY's random target, a target the
+        # f32 frame approximates to 30 dB (whole frame; worst 1024-ray subset), lowest self-PSNR against the f32 frame
+        cells = g(key, "gate_vs_exact_f32", "worst_abs_dpsnr_db") or {}
+        s[f"{tag}_gate_random_db"] = (cells.get("random") or {}).get("whole")
+        s[f"{tag}_gate_30db_worst_db"] = (cells.get("30dB") or {}).get("whole")
+        s[f"{tag}_gate_30db_1024rays_db"] = (cells.get("30dB") or {}).get("1024")
+        s[f"{tag}_gate_40db_worst_db"] = (cells.get("40dB") or {}).get("whole")
+        s[f"{tag}_self_psnr_min_db"] = g(key, "gate_vs_exact_f32", "min_self_psnr_db")
+    s["gate_frames"] = g("split_f16", "gate_vs_exact_f32", "frames_checked")
+    for prec, tag in (("f32", "f32"), ("f16x3", "f16"), ("bf16x3", "bf")):
+        s[f"train_ms_{tag}"] = g("train", prec, "ms_per_iter")
         ks = g("train", prec, "roofline", "kernels", default=[]) or []
-        for tag, k in zip(("fwd_save", "chain", "dw"), ks):
-            s[f"train_{prec}_{tag}_ms"] = k.get("avg_launch_ms")
-            s[f"train_{prec}_{tag}_frac"] = k.get("frac")
-            s[f"train_{prec}_{tag}_clock_mhz"] = k.get("sustained_clock_mhz")
-            s[f"train_{prec}_{tag}_ms_at_2400mhz"] = k.get("ms_at_nominal_clock")
+        for kt, k in zip(("fwd", "chain", "dw"), ks):
+            s[f"tr_{tag}_{kt}_ms"] = k.get("avg_launch_ms")
+            s[f"tr_{tag}_{kt}_frac"] = k.get("frac")                       # f32: executed / fp32-MFMA peak; split: algorithmic bytes / 8 TB/s
+            if prec != "f32":
+                s[f"tr_{tag}_{kt}_frac_mfma"] = k.get("frac_executed_mfma")   # issued 16-bit MFMA FLOPs / 2.5 PFLOP/s
+            s[f"tr_{tag}_{kt}_mhz"] = k.get("sustained_clock_mhz")
+            s[f"tr_{tag}_{kt}_ms_2400_est"] = k.get("ms_at_nominal_clock")    # ESTIMATE: busy cycles of ONE PMC dispatch / 2.4 GHz
     ar = g("train", "allreduce") or {}
     ps = g("config", "device", "pattern_store") or {}
     s.update({"train_allreduce_us": ar.get("allreduce_us"), "train_bytes_allreduced": ar.get("bytes_allreduced"),
               "train_ranks_seen": ar.get("ranks_seen"),
-              "hbm_fill_gbs": g("config", "device", "hbm_fill_gbs"), "hbm_copy_gbs": g("config", "device", "hbm_copy_gbs"),
-              "pattern_store_gbs": ps.get("stream_nt_gbs"), "pattern_store_rows_gbs": ps.get("rows_nt_gbs"),
-              "pattern_store_first_touch_gbs": ps.get("first_touch_stream_nt_gbs"), "pattern_store_seq_gbs": ps.get("seq_nt_gbs"),
-              "pattern_store_default_policy_gbs": ps.get("stream_gbs"), "pattern_store_rows_default_policy_gbs": ps.get("rows_gbs"),
+              "hbm_fill_gbs": g("config", "device", "hbm_fill_gbs"), "pattern_store_gbs": ps.get("stream_nt_gbs"),
               "engine_clock_mhz": g("config", "device", "engine_clock_mhz"),
               "eager_rocm_rays_s": g("eager_rocm", "value"), "eager_rocm_kind": g("eager_rocm", "kind"),
-              "eager_rocm_port_rays_s": g("eager_rocm", "port", "value"), "product_over_eager": g("eager_rocm", "product_over_eager"),
+              "eager_rocm_min_rays_s": g("eager_rocm", "value_min"), "eager_rocm_max_rays_s": g("eager_rocm", "value_max"),
+              "eager_rocm_frames": g("eager_rocm", "frames"),
+              "product_over_eager": g("eager_rocm", "product_over_eager"),
               "cpu_baseline_rays_s": g("cpu_baseline", "value"), "cpu_baseline_kind": g("cpu_baseline", "kind"),
-              "abs_dpsnr_db_f32": g("cpu_baseline", "parity_on_sample", "f32", "abs_dpsnr_db_fine"),
-              "abs_dpsnr_db_f16x3": g("cpu_baseline", "parity_on_sample", "f16x3", "abs_dpsnr_db_fine"),
-              "abs_dpsnr_db_f16x2": g("cpu_baseline", "parity_on_sample", "f16x2", "abs_dpsnr_db_fine"),
-              "abs_dpsnr_db_bf16x3": g("cpu_baseline", "parity_on_sample", "bf16x3", "abs_dpsnr_db_fine"),
+              "cpu_threads": g("cpu_baseline", "cores"),
               "tiny_rays_s": g("tiny", "value"), "tiny_cpu_rays_s": g("tiny", "cpu_baseline", "value"),
               "tiny_cpu_kind": g("tiny", "cpu_baseline", "kind"),
               "launcher_eval_frames_s": g("launcher", "launcher_eval_frames_s"),
-              "launcher_gpu_s_per_frame": g("launcher", "launcher_gpu_s_per_frame"),
               "launcher_wall_over_gpu": g("launcher", "launcher_wall_over_gpu")})
-    if s.get("split_f16x2_rays_s") and s.get("eager_rocm_rays_s"):
-        s["split_f16x2_over_eager"] = s["split_f16x2_rays_s"] / s["eager_rocm_rays_s"]       # north_star's ratio on its fastest gate-keeping arithmetic
+    # north_star's ratio "x the reference on the same GPU at matched PSNR": quoted on f16x3, the fastest arithmetic that keeps the gate at
+    # realistic targets (profiles/r06_gate_sensitivity.md); f16x2 / bf16x3 hold it against SURVEY's random target on whole frames only, so
+    # their ratios are SPEED figures, not matched-PSNR ones
+    if s.get("eager_rocm_rays_s"):
+        for tag in ("f16", "x2", "bf"):
+            if s.get(f"{tag}_rays_s"):
+                s[{"f16": "matched_psnr_over_eager_f16x3", "x2": "speed_only_over_eager_f16x2", "bf": "speed_only_over_eager_bf16x3"}[tag]] = \
+                    s[f"{tag}_rays_s"] / s["eager_rocm_rays_s"]
     pw = g("config", "device", "power") or {}
     st = pw.get("static") or {}
     s.update({"power_cap_w": st.get("power_cap_w"), "perf_level": st.get("perf_level")})
-    for prec in ("f32", "f16x3", "f16x2", "bf16x3", "train_fwd_bf16x3", "train_fwd_f32"):   # how THIS box holds its power cap under each kernel
-        o = pw.get(prec) or {}
-        s.update({f"power_w_{prec}": o.get("power_w"), f"sclk_mhz_{prec}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm")})
-        if prec.startswith("train_fwd"):
-            s[f"launch_ms_{prec}"] = o.get("launch_ms")             # back-to-back launches incl. the per-call allocation of `saved` (2.4 GB, cached)
-    s["fclk_mhz"] = (pw.get("f32") or {}).get("fclk_mhz_dpm")
+    for prec, tag in (("f32", "f32"), ("f16x3", "f16"), ("f16x2", "x2"), ("bf16x3", "bf"), ("train_fwd_bf16x3", "trfwd_bf"), ("train_fwd_f32", "trfwd_f32")):
+        o = pw.get(prec) or {}                                        # how THIS box holds its power cap under each kernel
+        s.update({f"w_{tag}": o.get("power_w"), f"mhz_{tag}": o.get("sclk_mhz_hwmon") or o.get("sclk_mhz_dpm")})
     return s
 
 

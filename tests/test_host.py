@@ -203,9 +203,17 @@ def test_bench_compact_line_fits_the_driver_record():
     line["eager_rocm"].update(kind="reference", port={"value": 255026.83364130167})
     import copy
     line["split_f16x2"] = copy.deepcopy(line["split_f16"])                 # round 5: the fourth arithmetic
-    for k in ("split_f16x2", "split_f16", "split_bf16"):
-        line[k]["whole_frame_vs_exact_f32"] = {"abs_dpsnr_db": 3.5123456789012345e-05, "self_psnr_db": 67.41234567890123, "frames_checked": 4,
-                                              "worst_abs_dpsnr_db": 5.6123456789012345e-05}
+    cells = {t: {m: 3.5123456789012345e-05 for m in ("whole", "3001", "1024")} for t in ("random", "20dB", "30dB", "40dB")}
+    for k in ("split_f16x2", "split_f16", "split_bf16"):                  # round 6: the gate per (target, ray count), nerf/gate.py
+        line[k]["gate_vs_exact_f32"] = {"frames_checked": 4, "min_self_psnr_db": 67.41234567890123, "max_self_psnr_db": 77.41234567890123,
+                                        "worst_abs_dpsnr_db": cells}
+        line[k]["roofline"].setdefault("frac_executed", 0.49123456789012345)
+        line[k]["roofline"].setdefault("sustained_clock_mhz", 2134.1234567890123)
+    line["per_rank_ms_per_step"] = [455.12345678901234]
+    line["eager_rocm"].update(value_min=231234.56789012345, value_max=241234.56789012345, frames=3)
+    for prec in ("f16x3", "bf16x3"):                                      # round 6: executed 16-bit MFMA fraction of the split training kernels
+        for k in line["train"][prec]["roofline"]["kernels"]:
+            k["frac_executed_mfma"] = 0.31234567890123456
     line["cpu_baseline"]["parity_on_sample"]["f16x2"] = dict(line["cpu_baseline"]["parity_on_sample"]["f16x3"])
     line["tiny"]["cpu_baseline"].update(kind="reference")
     line["summary"] = B.summary_of(line)
@@ -224,10 +232,12 @@ def test_bench_compact_line_fits_the_driver_record():
     assert all(not isinstance(v, (dict, list)) for v in c["summary"].values())
     assert all(not isinstance(v, (dict, list)) for k, v in c["roofline"].items())
     assert abs(c["value"] - line["value"]) <= 1e-5 * line["value"] and c["roofline"]["frac"] == round(line["roofline"]["frac"], 6)
-    for k in ("train_ms_per_iter_bf16x3", "train_bf16x3_fwd_save_ms_at_2400mhz", "split_f16_rays_s", "pattern_store_gbs", "product_over_eager",
-              "launcher_eval_frames_s", "launcher_gpu_s_per_frame", "eager_rocm_kind", "tiny_cpu_kind", "power_cap_w", "power_w_f16x3",
-              "sclk_mhz_f16x3", "pattern_store_default_policy_gbs", "split_f16x2_rays_s", "split_f16x2_over_eager", "split_f16x2_frame_abs_dpsnr_db"):
+    for k in ("train_ms_bf", "tr_bf_fwd_ms_2400_est", "tr_bf_fwd_frac_mfma", "tr_f16_chain_frac_mfma", "f16_rays_s", "pattern_store_gbs", "product_over_eager",
+              "launcher_eval_frames_s", "eager_rocm_kind", "eager_rocm_min_rays_s", "tiny_cpu_kind", "power_cap_w", "w_f16", "mhz_f16", "x2_rays_s",
+              "matched_psnr_over_eager_f16x3", "speed_only_over_eager_f16x2", "f16_gate_30db_worst_db", "x2_gate_30db_worst_db", "bf_gate_30db_worst_db",
+              "f16_gate_30db_1024rays_db", "x2_gate_random_db", "f16_self_psnr_min_db", "rank_ms_max", "cpu_threads"):
         assert k in c["summary"], k
+    assert "split_f16x2_over_eager" not in c["summary"]                   # (round 5's name read as a matched-PSNR ratio)
     # an overgrown summary sheds keys from the back instead of breaking the record
     line["summary"].update({f"pad_{i}": "x" * 40 for i in range(200)})
     c2 = B.compact_line(line)
