@@ -153,8 +153,8 @@ k_paper_mlp_fwd_encoded(const float* __restrict__ packed, const float* __restric
 // x87: (n_points, 87) pre-encoded inputs; cond: scratch of nf_paper_cond_floats() floats; out: (n_points, 4).
 extern "C" int nf_paper_forward_encoded(const float* packed, const float* x87, const float* expr76, const float* latent32,
                                         int64_t n_points, float* cond, float* out, nf_stream_t stream) {
+    if (n_points == 0) return 0;                           // nothing to do (empty tensors have NULL data pointers)
     if (!packed || !x87 || !expr76 || !latent32 || !cond || !out || n_points < 0) return NF_EINVAL;
-    if (n_points == 0) return 0;
     hipLaunchKernelGGL(k_paper_condition_encoded, dim3((nfl::COND_FLOATS + 255) / 256), dim3(256), 0, nf_s(stream), packed, expr76,
                        latent32, cond);
     constexpr int NT = NF_MLP_NT;

@@ -41,6 +41,7 @@ static void nf_lcode_table(std::vector<uint32_t>& t) {
         return r < 2 ? 256 + 6 * g + 3 * r : -1;
     });
     fill(OFF_RGB, 8, 1, 12, 3, 128, ident);
+    fill(OFF_DIRE, 18, 8, 8, 128, 280, [](int s) { return s < 280 ? s : -1; });
     for (int n = 0; n < 256; ++n)
         for (int k = 0; k < 108; ++k) t[OFF_WC1 + n * 108 + k] = code(0, n, 63 + k, 171);
     for (int n = 0; n < 128; ++n)
@@ -193,6 +194,149 @@ k_lcode_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
             if (p < n_points) reinterpret_cast<f32x4*>(raw)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
         }
     }
+}
+
+// ConditionalBlendshapeLearnableCodeNeRFModel.forward on PRE-ENCODED inputs (reference nerf/models.py:590-636 as called by run_network,
+// nerf/train_utils.py:9-33): x (P, 87) = [PE10(xyz) (63) | PE4(dirs) (24)] -> (P, 4).  Inference only; the hot path
+// (run_one_iter_of_nerf) never materialises x and uses nf_lcode_mlp_fwd.  Same body as k_lcode_mlp_fwd, inputs from x87, layers_dir.0
+// with its 24 direction columns as two register chunks (weights OFF_DIRE), bias table without the direction fold.
+__global__ void __launch_bounds__(256) k_lcode_condition_encoded(const float* __restrict__ packed, const float* __restrict__ expr,
+                                                                 const float* __restrict__ latent, float* __restrict__ cond) {
+    using namespace nlc;
+    __shared__ float cvec[108];
+    const int tid = threadIdx.x;
+    if (tid < 76) cvec[tid] = nf_div(nf_mul(expr[tid], 1.0f), 3.0f);
+    else if (tid < 108) cvec[tid] = latent[tid - 76];
+    __syncthreads();
+    const float* bias = packed + OFF_BIAS;
+    for (int i = blockIdx.x * blockDim.x + tid; i < COND_FLOATS; i += gridDim.x * blockDim.x) {
+        if (i >= B_CVEC) { cond[i] = i < B_DVEC ? cvec[i - B_CVEC] : 0.0f; continue; }
+        float v = bias[i];
+        if (i < B_X0) {
+            const float* w = packed + OFF_WC1 + i * 108;
+            float s = 0.0f;
+            for (int k = 0; k < 108; ++k) s = fmaf(w[k], cvec[k], s);
+            v += s;
+        }
+        cond[i] = v;
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NF_MLP_WAVES, 1)
+k_lcode_mlp_fwd_encoded(const float* __restrict__ packed, const float* __restrict__ cond, const float* __restrict__ x87, int64_t n_points,
+                        float* __restrict__ out) {
+    using namespace nlc;
+    __shared__ __attribute__((aligned(16))) f32x4 lds[NF_MLP_WAVES * 16 * NT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c = lane & 15;
+    const int64_t p0 = ((int64_t)blockIdx.x * NF_MLP_WAVES + wave) * (16 * NT);
+    if (p0 >= n_points) return;
+    f32x4* act4 = lds + wave * (16 * NT * 64);
+    f32x4 pe[NT][4];
+    f32x4 dirf[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        int64_t p = p0 + 16 * t + c;
+        if (p >= n_points) p = n_points - 1;
+        const float* row = x87 + p * 87;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int col = nfl::pe_slot_to_col(16 * j + 4 * g + r);
+                v[r] = col >= 0 ? row[col] : 0.0f;
+            }
+            pe[t][j] = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int s = 16 * j + 4 * g + r;
+                v[r] = s < 24 ? row[63 + s] : 0.0f;
+            }
+            dirf[t][j] = (f32x4){v[0], v[1], v[2], v[3]};
+        }
+    }
+    f32x4 acc[NT][16];
+    NfStream<NT> st;
+    f32x4 bj[NT];
+    float sigma_raw[NT];
+    const NfW Wi = nf_w_image(packed, PACKED), Ci = nf_w_image(cond, COND_FLOATS);
+#define NF_PE_B(J_) do { _Pragma("unroll") for (int t = 0; t < NT; ++t) bj[t] = pe[t][J_]; } while (0)
+    nf_load_bias<16>(st.bias, Ci, B_L1, lane);                           // layer1: no activation (M:609)
+    {
+        f32x4 w[16];
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4, lane);
+        NF_PE_B(0); nf_chunk<NT, 16, true>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 1 * 16 * 64, lane);
+        NF_PE_B(1); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 2 * 16 * 64, lane);
+        NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
+        nf_load_w16<16>(w, Wi, OFF_L1 / 4 + 3 * 16 * 64, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_X0 / 4, Ci, B_X0, act4, lane);
+    }
+#undef NF_PE_B
+    nf_seg_lds<NT, 16, true, false>(acc, st, Wi, OFF_X0 / 4, 16, act4, lane);       // reads layer1's output as stored
+    nf_pending_b<NT, false>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_X1 / 4, Ci, B_X1, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_X1 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_X2 / 4, Ci, B_X2, act4, lane);
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_X2 / 4, 16, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 1, 1>(acc, st.wb, bj, st, Wi, OFF_ALPHA / 4, Ci, B_ALPHA, act4, lane);
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_ALPHA / 4, 16, act4, lane);      // fc_alpha(x)
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 1, 0, 16, 1>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][0].x;
+    nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);      // feat = relu(fc_feat(x)): the ReLU is the reader's
+    nf_pending_b<NT, true>(bj, st);
+    nf_tail<NT, 16, 16, 8, 1>(acc, st.wb, bj, st, Wi, OFF_DIRE / 4, Ci, B_DIR, act4, lane);
+    {
+        f32x4 wd[16];
+        nf_load_w16<8>(wd, Wi, OFF_DIRE / 4 + 16 * 8 * 64, lane);                   // the first direction chunk's weights, a layer ahead
+        nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_DIRE / 4, 16, act4, lane);   // relu(layers_dir.0([feat | dir]))
+        nf_pending_b<NT, true>(bj, st);
+        nf_chunk<NT, 8, false>(acc, st.wb, bj, st.bias);
+        nf_load_w16<8>(st.wb, Wi, OFF_DIRE / 4 + 17 * 8 * 64, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
+        nf_chunk<NT, 8, false>(acc, wd, bj, st.bias);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) bj[t] = dirf[t][1];
+        nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    }
+    nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
+    nf_pending_b<NT, true>(bj, st);
+    nf_chunk<NT, 1, false>(acc, st.wb, bj, st.bias);
+    if (g == 0) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int64_t p = p0 + 16 * t + c;
+            if (p < n_points) reinterpret_cast<f32x4*>(out)[p] = (f32x4){acc[t][0].x, acc[t][0].y, acc[t][0].z, sigma_raw[t]};
+        }
+    }
+}
+
+// x87: (n_points, 87) pre-encoded inputs; cond: scratch of nf_lcode_cond_floats() floats; out: (n_points, 4).
+extern "C" int nf_lcode_forward_encoded(const float* packed, const float* x87, const float* expr76, const float* latent32,
+                                        int64_t n_points, float* cond, float* out, nf_stream_t stream) {
+    if (n_points == 0) return 0;                           // nothing to do (empty tensors have NULL data pointers)
+    if (!packed || !x87 || !expr76 || !latent32 || !cond || !out || n_points < 0) return NF_EINVAL;
+    hipLaunchKernelGGL(k_lcode_condition_encoded, dim3((nlc::COND_FLOATS + 255) / 256), dim3(256), 0, nf_s(stream), packed, expr76,
+                       latent32, cond);
+    constexpr int NT = NF_MLP_NT;
+    const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
+    const int64_t grid = (n_points + per_block - 1) / per_block;
+    if (grid > 0x7fffffff) return NF_EINVAL;
+    hipLaunchKernelGGL((k_lcode_mlp_fwd_encoded<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, cond, x87,
+                       n_points, out);
+    NF_RETURN_LAUNCH();
 }
 
 // Training forward (exact f32): the same arithmetic plus `saved` (layout nlc::S_*) -- every layer output as whole rows out of the

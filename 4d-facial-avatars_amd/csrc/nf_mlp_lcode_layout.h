@@ -20,7 +20,10 @@ constexpr int OFF_BIAS = OFF_WCD + 128 * 16;
 constexpr int B_L1 = 0, B_X0 = 256, B_X1 = 512, B_X2 = 768, B_FEAT = 1024, B_ALPHA = 1280, B_DIR = 1296, B_RGB = 1424;
 constexpr int BIAS_FLOATS = 1440;
 constexpr int B_CVEC = BIAS_FLOATS, B_DVEC = B_CVEC + 108, COND_FLOATS = B_DVEC + 16;
-constexpr int PACKED = OFF_BIAS + BIAS_FLOATS;
+// layers_dir.0 for PRE-ENCODED inputs (model.forward(x87, ...), nf_lcode_forward_encoded): 16 feat chunks + 2 chunks holding the 24
+// reference direction columns 256..279 in reference order (slot 256 + s <-> column 256 + s, s < 24), 8 tiles (cf. nfl::OFF_D0E)
+constexpr int OFF_DIRE = OFF_BIAS + BIAS_FLOATS;
+constexpr int PACKED = OFF_DIRE + 18 * 8 * FRAG;
 constexpr int NPARAMS = 16;   // layer1, layers_xyz.0..2, layers_dir.0, fc_alpha, fc_rgb, fc_feat (weight, bias each)
 
 // ---- training: activations saved by the forward, floats per point (section X of an n-point buffer starts at X * n) ----

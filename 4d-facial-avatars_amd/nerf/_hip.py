@@ -90,6 +90,7 @@ _PROTOTYPES = {
     "nf_paper_stream_table_bwd_bf16": (C.c_long, [_P, _Z]),
     "nf_lcode_stream_table_bf16": (C.c_long, [_P, _Z]),
     "nf_lcode_stream_table_bwd_bf16": (C.c_long, [_P, _Z]),
+    "nf_lcode_forward_encoded": (C.c_int, [_P, _P, _P, _P, _L, _P, _P, _P]),
     "nf_lcode_saved_floats": (_Z, [_L]),
     "nf_lcode_mlp_fwd_train": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _P, _P, _P]),
     "nf_lcode_packed_bwd_floats": (_Z, []),
@@ -129,7 +130,7 @@ _PROTOTYPES = {
 _OPTIONAL = set()
 # the revision of include/nerface_hip.h these prototypes were written for (nf_abi_version() of the library must equal it: a stale
 # .so with other signatures would take e.g. a stream pointer as `saved_f32` without any error)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def lib_path() -> str:

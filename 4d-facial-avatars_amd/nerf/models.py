@@ -338,7 +338,8 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         d_raw = d_raw.contiguous()
         dev = H.require_device(packed, cond, saved, d_raw)
         n_rays, n_samples = z.shape
-        ws_floats = lib.nf_lcode_bwd_workspace_floats(n_rays * n_samples)
+        with torch.cuda.device(dev):         # sized from the CURRENT device's CU count (nf_mlp_dw.h): ask on `dev`
+            ws_floats = lib.nf_lcode_bwd_workspace_floats(n_rays * n_samples)
         ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
         flat = torch.empty(lib.nf_lcode_grad_floats(), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
@@ -361,4 +362,25 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
         return grads, flat[off:off + 32]
 
     def forward(self, x, expr=None, latent_code=None, **kwargs):
-        raise NotImplementedError("evaluate this model through nerf.run_one_iter_of_nerf(...) (fused HIP kernel)")
+        """M:590-636 on pre-encoded inputs x (N, 87) = [PE10(xyz) | PE4(dirs)] -> (N, 4), as run_network calls it (T:9-33).
+        Inference only (kernel nf_lcode_forward_encoded); training goes through run_one_iter_of_nerf, whose fused kernels own
+        the backward."""
+        from . import _hip as H
+        if not self.fused_supported() or expr is None or latent_code is None:
+            raise NotImplementedError("forward() is built for the NeRFace geometry and needs expr and latent_code")
+        if torch.is_grad_enabled() and (x.requires_grad or latent_code.requires_grad or any(p.requires_grad for p in self.parameters())):
+            raise NotImplementedError("ConditionalBlendshapeLearnableCodeNeRFModel.forward has no autograd on the MI355X build: train "
+                                      "through nerf.run_one_iter_of_nerf(...), or call forward under torch.no_grad()")
+        x = ops._c(x.detach())
+        if x.dim() != 2 or x.shape[1] != 87:
+            raise ValueError("expected pre-encoded inputs of shape (N, 87)")
+        expr_d, lat_d = ops._c(expr.detach()).reshape(-1), ops._c(latent_code.detach()).reshape(-1)
+        packed = self._hip_packed()
+        dev = H.require_device(packed, x, expr_d, lat_d)
+        lib = H.lib()
+        cond = torch.empty(lib.nf_lcode_cond_floats(), dtype=torch.float32, device=dev)
+        out = torch.empty((x.shape[0], 4), dtype=torch.float32, device=dev)
+        with torch.cuda.device(dev):
+            H.check(lib.nf_lcode_forward_encoded(H.ptr(packed), H.ptr(x), H.ptr(expr_d), H.ptr(lat_d), x.shape[0], H.ptr(cond),
+                                                 H.ptr(out), H.stream_ptr(dev)), "nf_lcode_forward_encoded")
+        return out

@@ -451,7 +451,8 @@ def paper_mlp_bwd(model, packed, cond, z, d_raw, saved, split=False, exact_dw=Fa
     dev = H.require_device(packed, cond, saved_t, d_raw)
     lib = H.lib()
     n_rays, n_samples = z.shape
-    ws_floats = lib.nf_paper_bwd_workspace_floats(n_rays * n_samples)
+    with torch.cuda.device(dev):             # the slice plan behind the size depends on the CURRENT device's CU count (nf_mlp_dw.h): ask on `dev`
+        ws_floats = lib.nf_paper_bwd_workspace_floats(n_rays * n_samples)
     ws = torch.empty(ws_floats, dtype=torch.float32, device=dev)
     flat = torch.empty(lib.nf_paper_grad_floats(), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):

@@ -131,7 +131,8 @@ class _TinyRender(torch.autograd.Function):
         lib = H.lib()
         d_rgb = _c(d_rgb)
         d_raw = torch.empty_like(raw)
-        ws_n = lib.nf_tiny_bwd_workspace_floats(n * n_samples)
+        with torch.cuda.device(dev):
+            ws_n = lib.nf_tiny_bwd_workspace_floats(n * n_samples)
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
         flat = torch.empty(lib.nf_tiny_grad_floats(), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):

@@ -241,7 +241,12 @@ def test_train_step_f16x3_follows_the_f32_path(hip_lib, gpu, case):
     if case == "soft_train_noflip_64_64":
         assert worst < 1e-4 and e_lat < 1e-4
     else:
-        assert median < 3e-4 and worst < 2e-2 and e_lat < 1e-4
+        n_loose = sum(e >= 1.5e-3 for e in errs)
+        print(f"    {n_loose} of {len(errs)} tensors above 1.5e-3 (allowed: {MAX_LOOSE_TENSORS})")
+        assert median < 3e-4 and worst < 2e-2 and e_lat < 1e-4 and n_loose <= MAX_LOOSE_TENSORS
+
+
+MAX_LOOSE_TENSORS = 6            # of 48 (two networks x 24 live tensors)
 
 
 def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
@@ -285,6 +290,11 @@ def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
             assert nerrs[-1] <= 1e-2, (tag, k)
     errs.sort(), nerrs.sort()
     assert errs[len(errs) // 2] < 2e-4 and nerrs[len(nerrs) // 2] < 1e-4, (errs[len(errs) // 2], nerrs[len(nerrs) // 2])
+    # the loose per-tensor bound alone would let a defect confined to a few tensors through -- a flipped unit moves the
+    # tensors of ITS layer and the ones downstream of it, so only a handful may sit above the round-4 bound (1.5e-3)
+    n_loose = sum(e >= 1.5e-3 for e in errs)
+    print(f"train step: {n_loose} of {len(errs)} tensors above 1.5e-3 (allowed: {MAX_LOOSE_TENSORS})")
+    assert n_loose <= MAX_LOOSE_TENSORS, errs[-8:]
     e_lat = rel_l2(latent.grad.cpu(), lat.grad)
     e_ref = rel_l2(latent.grad.cpu(), torch.from_numpy(gold["latent"]))
     print(f"train step: worst param rel L2 {worst:.2e}, median {errs[len(errs) // 2]:.2e}; latent vs oracle(fp64) {e_lat:.2e}, vs reference autograd {e_ref:.2e}")

@@ -101,21 +101,30 @@ def test_fine_pass_on_oracle_depths(hip_lib, gpu, name):
     assert ((disp.cpu() - ref[4]).abs() / ref[4]).max() < 1e-5
 
 
-def test_psnr_gate_1e4_db(hip_lib, gpu):
-    """north_star gate: |PSNR(ours, target) - PSNR(reference, target)| <= 1e-4 dB on identical inputs."""
+# 1,024 rays against SURVEY 8(d)'s uniform-random target on the x1000-head test scene, per arithmetic: (gate on |dPSNR|, floor on the self-PSNR
+# against the CPU oracle).  f32 and f16x3 are held to the same bar; bf16x3 / f16x2 pass THIS (random-target) gate with their own self-PSNR
+# class -- what they do against realistic targets is tests/test_gpu_gate.py's subject (profiles/r06_gate_sensitivity.md).
+PSNR_GATE_1024 = {"f32": (1e-4, 90.0), "f16x3": (1e-4, 90.0), "bf16x3": (1e-4, 70.0), "f16x2": (1e-4, 60.0)}
+
+
+@pytest.mark.parametrize("precision", list(PSNR_GATE_1024))
+def test_psnr_gate_1e4_db(hip_lib, gpu, precision):
+    """north_star gate: |PSNR(ours, target) - PSNR(reference, target)| <= 1e-4 dB on identical inputs, 1,024 rays, all four arithmetics."""
     import nerf
     c = C.build_case("eval_det_64_128")
     c.update(n_rays=1024)
     ro, rd, bg, tgt, idx = C.ray_subset(512, 512, c["frame"], 1024, seed=99)
     c.update(ro=ro, rd=rd, bg=bg, tgt=tgt, idx=idx)
     ref = C.run_oracle(c)
+    nerf.set_mlp_precision(precision)
     out, *_ = U.run_product(nerf, c, gpu)
+    gate, floor = PSNR_GATE_1024[precision]
     for k in (0, 3):
         p_ref, p_our = O.psnr(ref[k], tgt), O.psnr(out[k].cpu(), tgt)
         self_psnr = O.psnr(out[k].cpu(), ref[k])
-        print(f"output {NAMES7[k]}: PSNR ref {p_ref:.6f} dB, ours {p_our:.6f} dB, |d|={abs(p_ref - p_our):.2e}, self-PSNR {self_psnr:.1f} dB")
-        assert abs(p_ref - p_our) <= 1e-4
-        assert self_psnr > 90.0
+        print(f"[{precision}] output {NAMES7[k]}: PSNR ref {p_ref:.6f} dB, ours {p_our:.6f} dB, |d|={abs(p_ref - p_our):.2e}, self-PSNR {self_psnr:.1f} dB")
+        assert abs(p_ref - p_our) <= gate
+        assert self_psnr > floor
 
 
 def test_validation_mode_shapes_and_chunking(hip_lib, gpu):
@@ -251,7 +260,7 @@ def test_no_background_prior(hip_lib, gpu):
         assert d <= TOL[n], (n, d)
 
 
-@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("precision", ["f32", "f16x3", "bf16x3", "f16x2"])
 def test_full_frame_512_properties(hip_lib, gpu, precision):
     """BASELINE configs[1] at its full size (512x512 rays, 64+128 samples, one frame), where the CPU oracle would take
     minutes: size-independent properties of the path instead --

@@ -1,7 +1,8 @@
 """'f16x2' (round 5): the split-fp16 forward with two products per weight (W_hi x_hi + W_lo x_hi), inference only.  GPU only.
 
 SURVEY §8(d) re-gated for this arithmetic, explicitly: (ii) the end-to-end gate of north_star -- |dPSNR| <= 1e-4 dB on whole frames -- is
-held as it stands (tests/test_gpu_e2e.py: test_full_frame_512_vs_fp64_oracle and its perturbed twin run "f16x2" beside the other
+held AGAINST SURVEY 8(d)'S UNIFORM-RANDOM TARGET (round 6: not against a target the render approximates to 30 dB on the x1000 head --
+tests/test_gpu_gate.py, profiles/r06_gate_sensitivity.md) (tests/test_gpu_e2e.py: test_full_frame_512_vs_fp64_oracle and its perturbed twin run "f16x2" beside the other
 arithmetics; tests/test_gpu_lcode.py the second family); (i) per point, the activations are rounded to fp16's 11 significand bits once
 per layer, so a raw output carries the sum of ~seven layers of 2^-12-class relative errors of its inputs, weighted by the (boosted) head:
 colours (fc_rgb x10): 1e-3 absolute max / 2e-4 rms (measured 2.4e-4 / 5.8e-5) against 2e-5 x scale for f32 / f16x3; density: relative to
@@ -50,7 +51,10 @@ def test_f16x2_raw_outputs(hip_lib, gpu, boost):
     print(f"[boost={boost}] f16x2 max|err| vs fp64 {['%.2e' % v for v in err(x2).tolist()]} rms {['%.2e' % v for v in rms(x2).tolist()]}; "
           f"f16x3 rms {['%.2e' % v for v in rms(x3).tolist()]}; bf16x3 rms {['%.2e' % v for v in rms(b3).tolist()]} (scale {['%.2g' % v for v in scale.tolist()]})")
     print(f"    density: T = {t_sigma:.3g}, max err / T = {float(err(x2)[3]) / t_sigma:.2e}, rms / T = {float(rms(x2)[3]) / t_sigma:.2e}")
-    assert torch.all(err(x2)[:3] <= 1e-3) and torch.all(rms(x2)[:3] <= 2e-4)                              # the stated per-point gates of this arithmetic
+    # REGRESSION PINS, not a parity statement: these bounds were written from the measurement (2.4e-4 max / 5.8e-5 rms
+    # colours, 9.5e-4 T / 2.4e-4 T density) with a 4x allowance; f16x2 is not an fp32-class arithmetic per point, and what it does to
+    # north_star's gate is measured in tests/test_gpu_gate.py (it holds it against a uniform-random target only on the x1000 head)
+    assert torch.all(err(x2)[:3] <= 1e-3) and torch.all(rms(x2)[:3] <= 2e-4)
     assert float(err(x2)[3]) <= 2e-3 * t_sigma and float(rms(x2)[3]) <= 4e-4 * t_sigma
     assert torch.all(rms(x3) <= 0.05 * rms(x2))                                                          # (and f16x3 really is another class)
     assert bool(torch.isfinite(x2).all())
@@ -103,7 +107,9 @@ def test_f16x2_against_golden_reference(hip_lib, gpu, name):
 
 
 def test_f16x2_gate_over_frames_of_the_bench_scene(hip_lib, gpu):
-    """north_star's gate is a property of a frame, and it varies by an order of magnitude from frame to frame: eight whole 512 x 512 frames
+    """(AGAINST A UNIFORM-RANDOM TARGET -- SURVEY 8(d)'s, PSNR ~ 8 dB: the least sensitive target there is; against a target the render
+    approximates to 30 dB the same frames miss the gate by 43x: tests/test_gpu_gate.py, profiles/r06_gate_sensitivity.md.)
+    north_star's gate is a property of a frame, and it varies by an order of magnitude from frame to frame: eight whole 512 x 512 frames
     of bench.py's scene (the x1000 density head -- the harshest scene of this repository -- its poses, expressions and latent codes, a fresh
     random target per frame, `perturb` on with seeded draws) in "f16x2" against the product's exact-f32 frame: every frame <= 1e-4 dB
     (measured over 16 frames: median 9e-6, worst 5.6e-5 on frame 1; f16x3 <= 6e-7, bf16x3 <= 8e-6; profiles/r05_c19/frame_gate_sweep.txt)."""

@@ -194,6 +194,28 @@ def test_bench_bare_gpus_2_launches_its_own_ranks(hip_lib, gpu):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--no-extras"],
                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
     assert r.returncode != 0 and b"must agree" in r.stderr
+    # per-rank step times on the line: stragglers show
+    assert len(d["per_rank_ms_per_step"]) == 2 and c["summary"]["rank_ms_max"] >= c["summary"]["rank_ms_min"] > 0
+    assert abs(c["summary"]["rank_ms_max"] - c["ms_per_step"]) <= 1e-3 * c["ms_per_step"]        # the job's time is the slowest rank's
+
+
+def test_bench_more_ranks_than_devices_fails_fast_with_the_reason(hip_lib, gpu):
+    """`bench.py --gpus N` with the nccl (RCCL) backend on a box with fewer than N devices must exit non-zero within a
+    minute with a message naming device_count -- not hang in the rendezvous or inside ncclCommInitRank.  Both entry forms: the bare
+    command (it would launch its own ranks) and a rank started by a launcher."""
+    import subprocess
+    import time
+    import torch
+    n = torch.cuda.device_count() + 1
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "NERFACE_DIST_BACKEND"):
+        env.pop(k, None)
+    for extra in ({}, {"WORLD_SIZE": str(n), "RANK": "0", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29999"}):
+        t0 = time.time()
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--no-extras"],
+                           env=dict(env, **extra), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=120)
+        assert r.returncode != 0 and b"device_count" in r.stderr, r.stderr.decode()[-2000:]
+        assert time.time() - t0 < 60.0
 
 
 def _torchrun(n, port):

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libnerface_hip.so does not export {name}"
     from nerf import _hip
-    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 3          # exact: the ctypes prototypes are written for ONE revision
+    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 4          # exact: the ctypes prototypes are written for ONE revision
     assert b"gfx950" in hip_lib.nf_build_info()
     assert hip_lib.nf_error_string(-22).startswith(b"nerface_hip")
 
