@@ -31,6 +31,9 @@ On the same JSON line (every BASELINE config that fits this box is timed by this
                   host cores on a bounded sample of the same workload (rank 0, N=1 only), the oracle port beside it on a slice;
                   kind "port" (labelled fallback) only where neither is present.
   summary      -- LAST key of the line: flat scalars (the driver's record keeps only the tail of the line).
+
+Files: bench.py (this: the timed regions, the training object, the line), bench_common.py (workload constants, synthetic scene),
+bench_baselines.py (cpu_baseline / eager_rocm legs -- the only importers of oracle/), bench_probes.py (device, power, PMC, launcher legs).
 """
 from __future__ import annotations
 
@@ -55,214 +58,12 @@ for _p in (ROOT, PKG):
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-H = W = 512
-N_COARSE, N_FINE = 64, 128
-CHUNK = 65536
-FLOP_PER_POINT = 1_100_032            # algorithmic forward FLOPs of the paper MLP per point
-EXEC_FLOP_PER_POINT_F32 = 999_936     # FLOPs the exact-f32 kernel issues per point: the folded constant columns never enter the GEMMs
-CHAIN_FLOP_PER_POINT = 918_784        # dX chain: 2 x (3*128 + 2*128*128 + 128*256 + 256 + 6*256*256)
-DW_FLOP_PER_POINT = 1_100_032         # weight gradients: one outer product per weight = the forward's products
-PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
-PEAK_HBM_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3 TB/s is achievable)
-PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
-BF16X3_EXEC_FLOP_PER_POINT = 3012 * 32768 / 32   # executed MFMA FLOPs per point of the split-bf16 kernel (3012 MFMAs / 32 points)
-INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
-NEAR, FAR = 0.2, 0.8
-CPU_CALIBRATION_RAYS = 4096           # slice of the CPU sample on which the thread count of the reference's CPU run is chosen
-
-
-def synth_params(seed, device, family="paper"):
-    """Random-init weights of the paper architecture (torch default nn.Linear init) with a density boost so
-    that rays are neither all-empty nor all-opaque.  family="lcode": the second model family (--mode train only)."""
-    import nerf
-    torch.manual_seed(seed)
-    cls = nerf.models.ConditionalBlendshapePaperNeRFModel if family == "paper" else nerf.models.ConditionalBlendshapeLearnableCodeNeRFModel
-    m = cls(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True, include_input_dir=False, use_viewdirs=True,
-            num_layers=4, hidden_size=256, include_expression=True)
-    with torch.no_grad():
-        m.fc_alpha.weight.mul_(1000.0)
-        m.fc_alpha.bias.fill_(5.0)
-        m.fc_rgb.weight.mul_(10.0)
-    return m.to(device).eval()
-
-
-def frame_pose(f):
-    import math
-    a = 0.3 * math.sin(2 * math.pi * f / 100.0)
-    b = 0.15 * math.cos(2 * math.pi * f / 100.0)
-    ry = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]])
-    rx = np.array([[1, 0, 0], [0, math.cos(b), -math.sin(b)], [0, math.sin(b), math.cos(b)]])
-    m = np.eye(4)
-    m[:3, :3] = ry @ rx
-    m[:3, 3] = [0.02 * math.sin(2 * math.pi * f / 100.0), 0.02 * math.cos(2 * math.pi * f / 100.0), 0.5]
-    return torch.tensor(m, dtype=torch.float32)
-
-
-def options(nerf, chunk=CHUNK):
-    mode = dict(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=chunk, perturb=True, lindisp=False,
-                radiance_field_noise_std=0.0, white_background=False)
-    return nerf.CfgNode(dict(nerf=dict(use_viewdirs=True, train=dict(mode), validation=dict(mode)),
-                             dataset=dict(no_ndc=True, near=NEAR, far=FAR)))
-
-
-def _reference_cpu_run(n_rays, c, cores):
-    """The reference's OWN CPU path on this box's host cores: the unmodified `get_ray_bundle` (H:68-123) for the whole 512x512
-    frame plus the unmodified `run_one_iter_of_nerf` (T:165-290) on `n_rays` rays of it, imported from the live tree or from
-    oracle/_ref/nerface_ref.zip (oracle/make_ref.py packs the untouched files; the archive travels with the push).  Returns
-    (outputs, seconds of run_one_iter_of_nerf on the sample, seconds of the full-frame get_ray_bundle, threads, kind string)."""
-    from oracle import make_golden as MG
-    from oracle import nerface_oracle as O
-    from oracle import ref_import as RI
-    ref = RI.import_reference()
-    warm = dict(c)
-    warm.update(ro=c["ro"][:256], rd=c["rd"][:256], bg=c["bg"][:256])
-    n_cal = min(n_rays, CPU_CALIBRATION_RAYS)
-    cal = dict(c)
-    cal.update(ro=c["ro"][:n_cal], rd=c["rd"][:n_cal], bg=c["bg"][:n_cal])
-    best, best_t, table = cores, None, {}
-    with torch.no_grad():
-        # torch-CPU GEMMs of this size do not scale to every hardware thread of a big host, and the best count depends on the GEMM's
-        # M: calibrate on a slice of the timed sample's order (4096 rays = 786k MLP points per fine call; round 5 used 256 rays, which
-        # favours few threads -- VERDICT r05 weak #7) over {16, 32, 64, 128, all}, then time the sample with the winner (`cores`)
-        MG.run_reference(ref, warm)
-        for nt in sorted({min(cores, k) for k in (16, 32, 64, 128, cores)}):
-            torch.set_num_threads(nt)
-            t0 = time.perf_counter()
-            MG.run_reference(ref, cal)
-            t = time.perf_counter() - t0
-            table[nt] = n_cal / t
-            if best_t is None or t < best_t:
-                best, best_t = nt, t
-            if t > 4.0 * best_t:                                            # far off the best: larger counts will not recover
-                break
-        _reference_cpu_run.calibration = {"rays": n_cal, "rays_per_s_by_threads": table}
-        torch.set_num_threads(best)
-        pose = O.frame_pose(c["frame"])[:3, :4]
-        ref.get_ray_bundle(H, W, INTRINSICS, pose)
-        t0 = time.perf_counter()
-        ref.get_ray_bundle(H, W, INTRINSICS, pose)
-        t_bundle = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        out, _ = MG.run_reference(ref, c)
-        dt = time.perf_counter() - t0
-    return out, dt, t_bundle, best, RI.reference_kind()
-
-
-def cpu_baseline(n_rays=12288):
-    """The CPU baseline beside the headline, on a bounded sample: n_rays rays of one 512^2 frame, 64+128 samples.
-    kind "reference": the UNMODIFIED reference code timed on this box (see _reference_cpu_run); the oracle port is timed on a
-    slice of the same rays beside it (`port`).  kind "port" (labelled fallback): only when neither /root/reference nor
-    oracle/_ref/ is present."""
-    from oracle import cases as C
-    from oracle import nerface_oracle as O
-    from oracle import ref_import as RI
-    cores = os.cpu_count() or 1
-    c = C.build_case("eval_det_64_128")
-    ro, rd, bg, _, _ = C.ray_subset(H, W, 3, n_rays, seed=5)
-    c.update(ro=ro, rd=rd, bg=bg)
-    warm = dict(c)
-    warm.update(ro=ro[:256], rd=rd[:256], bg=bg[:256])
-    kind, ref_detail, port_detail = "port", None, None
-    if RI.reference_importable():
-        try:
-            ref, dt, t_bundle, best, how = _reference_cpu_run(n_rays, c, cores)
-            kind = "reference"
-            t_total = dt + t_bundle * n_rays / float(H * W)                # the frame's ray bundle, charged per ray
-            ref_detail = {"run_one_iter_of_nerf_s": dt, "get_ray_bundle_full_frame_s": t_bundle, "imported_from": how,
-                          "thread_calibration": getattr(_reference_cpu_run, "calibration", None)}
-            # the oracle port on a slice of the same rays, same threads: how close the restatement's speed is to the real thing
-            n_port = min(n_rays, 2048)
-            cp = dict(c)
-            cp.update(ro=ro[:n_port], rd=rd[:n_port], bg=bg[:n_port])
-            with torch.no_grad():
-                C.run_oracle(warm)
-                t0 = time.perf_counter()
-                got = C.run_oracle(cp)
-                dtp = time.perf_counter() - t0
-            port_detail = {"value": n_port / dtp, "unit": "rays/s", "rays": n_port,
-                           "bit_identical_to_reference_on_slice": bool(all(torch.equal(a, b[:n_port]) for a, b in zip(got, ref)))}
-        except Exception as e:                                              # never lose the baseline to the stronger leg
-            kind, ref_detail = "port", {"reference_error": repr(e)}
-    if kind == "port":
-        best, best_t = cores, None
-        with torch.no_grad():
-            for nt in sorted({min(cores, k) for k in (16, 32, 64, cores)}):
-                torch.set_num_threads(nt)
-                C.run_oracle(warm)
-                t0 = time.perf_counter()
-                C.run_oracle(warm)
-                t = time.perf_counter() - t0
-                if best_t is None or t < best_t:
-                    best, best_t = nt, t
-            torch.set_num_threads(best)
-            t0 = time.perf_counter()
-            ref = C.run_oracle(c)
-            dt = time.perf_counter() - t0
-        t_total = dt
-    # parity of the product on exactly this sample (same rays, weights, conditioning; deterministic sampling): the
-    # north-star gate |PSNR(ours, target) - PSNR(reference algorithm, target)| <= 1e-4 dB, in both precisions
-    parity = {}
-    try:
-        import nerf
-        from tests import util as U
-        tgt = C.ray_subset(H, W, 3, n_rays, seed=5)[3]
-        keep = nerf.get_mlp_precision()
-        for prec in ("bf16x3", "f16x3", "f16x2", "f32"):
-            nerf.set_mlp_precision(prec)
-            out, *_ = U.run_product(nerf, c, torch.device("cuda", torch.cuda.current_device()))
-            parity[prec] = {"abs_dpsnr_db_fine": abs(O.psnr(out[3].cpu(), tgt) - O.psnr(ref[3], tgt)),
-                            "abs_dpsnr_db_coarse": abs(O.psnr(out[0].cpu(), tgt) - O.psnr(ref[0], tgt)),
-                            "self_psnr_db_fine": O.psnr(out[3].cpu(), ref[3])}
-        nerf.set_mlp_precision(keep)
-        # raw MLP outputs of the three kernels against an fp64 evaluation of the oracle MLP on the same 64 x 192 points: the
-        # evidence behind "fp32-class" for the split-fp16 kernel (rms error per output channel [r, g, b, sigma])
-        from nerf import ops
-        dev = torch.device("cuda", torch.cuda.current_device())
-        g = torch.Generator().manual_seed(5)
-        zz = torch.sort(torch.rand((64, 192), generator=g) * (FAR - NEAR) + NEAR, dim=-1)[0]
-        r0, d0 = ro[:64], rd[:64]
-        p64 = {k: v.double() for k, v in c["p_fine"].items()}
-        want = O.paper_mlp(p64, O.encode_points(r0.double(), d0.double(), zz.double(), NEAR, FAR), c["expr"].double(),
-                           c["latent"].double()).reshape(64, 192, 4)
-        hw = U.make_model(nerf, c["p_fine"], dev).hip_weights()
-        cond = ops.paper_condition(hw.get(), c["expr"].to(dev), c["latent"].to(dev), NEAR, FAR)
-        dv = lambda t: t.to(dev).contiguous()
-        got = {"f32": ops.paper_mlp_fwd(hw.get(), cond, dv(r0), dv(d0), dv(zz)),
-               "f16x3": ops.paper_mlp_fwd_f16(hw.get_f16(), cond, dv(r0), dv(d0), dv(zz)),
-               "f16x2": ops.paper_mlp_fwd_f16x2(hw.get_f16(), cond, dv(r0), dv(d0), dv(zz)),
-               "bf16x3": ops.paper_mlp_fwd_bf16(hw.get_bf16(), cond, dv(r0), dv(d0), dv(zz))}
-        parity["mlp_rms_error_vs_fp64"] = {k: (v.cpu().double() - want).pow(2).mean(dim=(0, 1)).sqrt().tolist() for k, v in got.items()}
-        parity["mlp_output_scale"] = want.abs().amax(dim=(0, 1)).tolist()
-    except Exception as e:                                    # the baseline number must not depend on this extra
-        parity = {"error": repr(e)}
-    what = ("UNMODIFIED reference get_ray_bundle + run_one_iter_of_nerf (torch-CPU fp32)" if kind == "reference"
-            else "fp32 torch-CPU oracle (port of the reference path; oracle/_ref absent on this box)")
-    return {"value": n_rays / t_total, "unit": "rays/s", "cores": torch.get_num_threads(), "threads": torch.get_num_threads(),
-            "host_cores": os.cpu_count(), "kind": kind,
-            "cores_note": "`cores` = torch CPU threads the calibration picked for the timed sample; `host_cores` = os.cpu_count() of this box",
-            "reference": ref_detail, "port": port_detail,
-            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, {what}, {t_total:.1f} s",
-            "parity_on_sample": parity}
-
-
-# algorithmic HBM bytes per MLP point of the three training kernels of the PAPER model (csrc/nf_mlp_layout.h): the forward writes the
-# saved activations + ReLU bit masks (and reads z), the chain reads its ReLU masks + d_raw and writes dZ, the weight-gradient
-# GEMMs read every saved activation, every dZ and d_raw once
-TRAIN_KERNELS = {
-    "f32": (("k_paper_mlp_fwd_save", "forward with saves"), ("k_paper_mlp_bwd_chain_masks", "dX chain"), ("k_dw_gemm_lds", "weight-gradient GEMMs")),
-    "bf16x3": (("k_paper_mlp_fwd_bf16_train", "forward with saves"), ("k_paper_mlp_bwd_chain_bf16", "dX chain"), ("k_paper_dw_gemm_bf16", "weight-gradient GEMMs")),
-    "f16x3": (("k_paper_mlp_fwd_f16_train", "forward with saves"), ("k_paper_mlp_bwd_chain_f16", "dX chain"), ("k_paper_dw_gemm_f16", "weight-gradient GEMMs")),
-}
-TRAIN_BYTES_PER_POINT = (4 * (2256 + 72) + 4 + 16, 4 * 72 + 16 + 4 * 2176, 4 * (2256 + 2176 + 4))
-TRAIN_FLOP_PER_POINT = (FLOP_PER_POINT, CHAIN_FLOP_PER_POINT, DW_FLOP_PER_POINT)
-# issued 16-bit MFMA FLOPs per point of the split training kernels: v_mfma_f32_32x32x16 = 32768 FLOPs per 32 points; the forward with
-# saves issues 3284 per wave tile (3012 + 272 transposing ones), the dX chain 2760 (static counts of the ISA, tools/isa_summary.py),
-# the weight-gradient GEMMs three products per algorithmic one
-TRAIN_SPLIT_EXEC_FLOP_PER_POINT = (3284 * 1024, 2760 * 1024, 3 * DW_FLOP_PER_POINT)
-# (lcode family, --mode train --family lcode: whole-iteration bytes only)
-LCODE_BYTES_PER_POINT = {"f32": 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
-                         "bf16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
-                         "f16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4)}
+# the workload's constants and synthetic scene (bench.INTRINSICS, bench.synth_params, ... stay importable from here), the baseline legs
+# (the only importers of oracle/ outside tests/) and the probe legs (device / power / PMC / launcher): VERDICT r05 housekeeping
+from bench_common import *  # noqa: E402,F401,F403
+from bench_baselines import cpu_baseline, cpu_baseline_tiny, eager_rocm_baseline, eager_rocm_reference  # noqa: E402,F401
+from bench_probes import (_pmc_guard, device_info, launcher_eval_leg, pattern_store_probe, pmc_kernel_bytes, pmc_pass_rows,  # noqa: E402,F401
+                          pmc_sustained_clock, pmc_traffic, pmc_train_clocks, pmc_train_traffic, power_probe)
 
 
 def train_roofline(args, model, dev, n_rays):
@@ -320,12 +121,19 @@ def train_roofline(args, model, dev, n_rays):
         ws_floats = lib.nf_paper_bwd_workspace_floats(n)
         ws = torch.empty(ws_floats, device=dev)
         ms = [0.0, 0.0, 0.0, 0.0]
+        fwd = lambda: ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd, packed_b=pk_fwd if prec == "bf16x3" else None,
+                                              packed_h=pk_fwd if prec == "f16x3" else None)
         for it in range(reps + 2):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            # the timed launch queues behind an untimed one of the same kernel: round 5 recorded e0 on an IDLE stream (the backward call
+            # below synchronises), so e0 -> e1 also held the host's 30-60 us between the event and the launch (two torch.empty, the ctypes
+            # call) and the clock ramp of a GPU that had gone idle -- 2-4 % of a 1-2 ms kernel that runs behind other kernels in a real
+            # iteration.  The backward stages were always timed by events recorded inside ONE C call, back to back on a busy queue.
+            del_me = fwd()
             e0.record()
-            raw, (saved,) = ops.paper_mlp_fwd_train(packed, cond, ro, rd, z, rd, packed_b=pk_fwd if prec == "bf16x3" else None,
-                                                    packed_h=pk_fwd if prec == "f16x3" else None)
+            raw, (saved,) = fwd()
             e1.record()
+            del del_me
             st = (C.c_float * 3)()
             HH.check(lib.nf_paper_mlp_bwd_stage_ms(HH.ptr(packed), HH.ptr(pk_bwd), code, HH.ptr(cond), HH.ptr(saved), HH.ptr(d_raw), n_rays, s_,
                                                    HH.ptr(ws), ws_floats, HH.ptr(flat), st, HH.stream_ptr(dev)), "nf_paper_mlp_bwd_stage_ms")
@@ -537,475 +345,6 @@ def bench_tiny(dev, steps=20):
                                    "what": "the same iteration captured once in a HIP graph and replayed (GraphedTinyTrainer)"}},
            "note": "host-launch bound on the device (ray bundle + two kernels per image of 4096 rays)"}
     return res, ({k: v.detach().cpu() for k, v in model.state_dict().items()}, pose, focal)
-
-
-def cpu_baseline_tiny(params, pose, focal, reps=3):
-    """configs[0] on the host, kind "reference": the UNMODIFIED tiny_nerf.py's own `run_one_iter_of_tinynerf` (TN:111-159) with its
-    own VeryTinyNerfModel on the same weights / pose (imported through oracle/ref_import.import_reference_tiny: live tree or the
-    travelling archive); the oracle port of the same image beside it.  kind "port" only where the reference is absent."""
-    from oracle import nerface_oracle as O
-    from oracle import ref_import as RI
-    torch.set_num_threads(min(os.cpu_count() or 1, 16))                 # 131k points x 128 features: more threads only add overhead
-    with torch.no_grad():
-        O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            O.tiny_render(params, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=torch.zeros(64, 64, 32))
-        port_ms = 1e3 * (time.perf_counter() - t0) / reps
-    port = {"value": 4096 / (port_ms * 1e-3), "unit": "rays/s", "ms_per_image": port_ms, "kind": "port"}
-    if RI.reference_importable():
-        try:
-            ref = RI.import_reference()
-            TN = RI.import_reference_tiny()
-            tm = TN.VeryTinyNerfModel(num_encoding_functions=10)
-            tm.load_state_dict(params)
-            enc = ref.positional_encoding                                  # what the script passes (TN:230, 288)
-            with torch.no_grad():
-                TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, enc, ref.get_minibatches, 16384, tm, 10)
-                t0 = time.perf_counter()
-                for _ in range(reps):
-                    TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, enc, ref.get_minibatches, 16384, tm, 10)
-                cpu_ms = 1e3 * (time.perf_counter() - t0) / reps
-            return {"value": 4096 / (cpu_ms * 1e-3), "unit": "rays/s", "ms_per_image": cpu_ms, "cores": torch.get_num_threads(),
-                    "kind": "reference", "sample": f"{reps} whole 64x64x32 images, UNMODIFIED tiny_nerf.run_one_iter_of_tinynerf (torch-CPU fp32)",
-                    "imported_from": RI.reference_kind(), "port": port}
-        except Exception as e:
-            port["reference_error"] = repr(e)
-    return {**port, "cores": torch.get_num_threads(), "sample": f"{reps} whole 64x64x32 images (oracle port)"}
-
-
-def eager_rocm_baseline(dev, n_rays=32768, chunk=8192):
-    """The same-GPU stock-PyTorch denominator (BASELINE.md sections 1, 3): the reference ALGORITHM as PyTorch-ROCm eager fp32 ops on this
-    device -- the oracle's torch restatement with its tensors moved to the GPU, rays fed `chunk` at a time (the reference's 65536-ray
-    chunks would need > 4 GB per concatenated MLP input) -- on a bounded sample of the headline workload (n_rays rays of one 512x512
-    frame, 64+128 samples, deterministic sampling).  A baseline leg like cpu_baseline: the oracle is the thing timed, never the product."""
-    from oracle import cases as C
-    from oracle import nerface_oracle as O
-    c = C.build_case("eval_det_64_128")
-    ro, rd, bg, _, _ = C.ray_subset(H, W, 3, n_rays, seed=5)
-    pc = {k: v.to(dev) for k, v in c["p_coarse"].items()}
-    pf = {k: v.to(dev) for k, v in c["p_fine"].items()}
-    ro, rd, bg = ro.to(dev), rd.to(dev), bg.to(dev)
-    expr, lat = c["expr"].to(dev), c["latent"].to(dev)
-
-    def run():
-        outs = []
-        with torch.no_grad():
-            for i in range(0, n_rays, chunk):
-                r = min(chunk, n_rays - i)
-                z = O.coarse_z(r, O.NEAR, O.FAR, 64, None).to(dev)
-                raw = O.paper_mlp(pc, O.encode_points(ro[i:i + r], rd[i:i + r], z, O.NEAR, O.FAR), expr, lat).reshape(r, 64, 4).clone()
-                raw[:, -1, :3] = bg[i:i + r]
-                _, _, _, w = O.volume_render(raw, z, rd[i:i + r], None, True)
-                zm = 0.5 * (z[:, 1:] + z[:, :-1])
-                u = torch.linspace(0, 1, 128, device=dev).expand(r, 128)
-                zs = O.sample_pdf(zm, w[:, 1:-1], 128, u)
-                zf, _ = torch.sort(torch.cat((z, zs), -1), -1)
-                raw = O.paper_mlp(pf, O.encode_points(ro[i:i + r], rd[i:i + r], zf, O.NEAR, O.FAR), expr, lat).reshape(r, 192, 4).clone()
-                raw[:, -1, :3] = bg[i:i + r]
-                outs.append(O.volume_render(raw, zf, rd[i:i + r], None, True)[0])
-        return torch.cat(outs)
-    run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    out = run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    assert bool(torch.isfinite(out).all())
-    return {"value": n_rays / dt, "unit": "rays/s", "kind": "port", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
-            "sample": f"{n_rays} rays of one 512x512 frame, 64+128 samples, ray chunk {chunk}, oracle ops on {torch.cuda.get_device_name(dev)}, {dt * 1e3:.0f} ms",
-            "note": "stock PyTorch-ROCm eager execution of the reference algorithm on the same GPU; the reference's own scripts cannot run on this box"}
-
-
-def eager_rocm_reference(dev, n_frames=3):
-    """The same-GPU denominator of north_star ("the reference PyTorch-CUDA rays/sec"): the UNMODIFIED reference's `get_ray_bundle`
-    (H:68-123) + `run_one_iter_of_nerf` (T:165-290, mode="validation") with both models and every tensor on this MI355X, executed by
-    stock PyTorch-ROCm eager -- whole 512x512 frames, 64+128 samples, chunksize 65536 and perturb on as shipped (CFG:156), after a
-    one-chunk warm-up; `n_frames` frames timed one by one (synchronised), median reported with the spread.  A baseline leg: imported out of /root/reference or oracle/_ref/nerface_ref.zip, never
-    part of the product or of the timed region of the headline."""
-    from oracle import cases as C
-    from oracle import make_golden as MG
-    from oracle import nerface_oracle as O
-    from oracle import ref_import as RI
-    ref = RI.import_reference()                                             # (raises when the reference did not travel)
-    c = C.build_case("eval_det_64_128")
-    mc, mf = MG.ref_model(ref, c["p_coarse"]).to(dev).eval(), MG.ref_model(ref, c["p_fine"]).to(dev).eval()
-    opt = MG.ref_options(ref, N_COARSE, N_FINE, True, 0.0)                  # chunksize 65536, perturb on, noise 0: the shipped validation block
-    enc_xyz = ref.get_embedding_function(num_encoding_functions=10, include_input=True, log_sampling=True)
-    enc_dir = ref.get_embedding_function(num_encoding_functions=4, include_input=False, log_sampling=True)
-    pose = O.frame_pose(c["frame"])[:3, :4].to(dev)
-    bg = O.synthetic_image(H, W, 7).reshape(-1, 3).to(dev)
-    expr, lat = c["expr"].to(dev), c["latent"].to(dev)
-
-    def frame(rows):
-        with torch.no_grad():
-            ro, rd = ref.get_ray_bundle(H, W, INTRINSICS, pose)
-            ro, rd = ro[:rows], rd[:rows]
-            return ref.run_one_iter_of_nerf(rows, W, INTRINSICS, mc, mf, ro, rd, opt, mode="validation", encode_position_fn=enc_xyz,
-                                            encode_direction_fn=enc_dir, expressions=expr, background_prior=bg[:rows * W], latent_code=lat)
-    frame(CHUNK // W)                                                       # warm-up: one 65536-ray chunk (rocBLAS / hipBLASLt plans, allocator)
-    torch.cuda.synchronize()
-    peak0 = torch.cuda.max_memory_allocated(dev)
-    times = []
-    for _ in range(n_frames):                                               # whole frames, each synchronised; the MEDIAN is the figure
-        t0 = time.perf_counter()
-        out = frame(H)
-        torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
-    dt = sorted(times)[len(times) // 2]
-    return {"value": H * W / dt, "unit": "rays/s", "kind": "reference", "dtype": "f32 (torch eager ops, rocBLAS/hipBLASLt GEMMs)",
-            "frames": n_frames, "frame_ms": [1e3 * t for t in times], "value_min": H * W / max(times), "value_max": H * W / min(times),
-            "sample": f"median of {n_frames} whole 512x512 frames ({H * W} rays each), 64+128 samples, chunksize 65536, perturb on, UNMODIFIED reference "
-                      f"get_ray_bundle + run_one_iter_of_nerf on {torch.cuda.get_device_name(dev)} (PyTorch-ROCm eager), {dt * 1e3:.0f} ms",
-            "imported_from": RI.reference_kind(), "peak_device_bytes": int(max(peak0, torch.cuda.max_memory_allocated(dev)))}
-
-
-def launcher_eval_leg(dev, model_c, model_f, n_frames=32):
-    """configs[3] readiness: launch/eval_sharded.py itself on a synthetic 512x512 sequence of n_frames test frames in the on-disk
-    format (tools/make_synthetic_dataset.py), one GPU, f32, PNG + normal-map output -- frames/s of the loop's WALL time (including
-    the PNG tail) against the GPU seconds per frame its HIP events measure: wall / GPU ~ 1 means the sequence render is not
-    host-bound (EV:392-498 with EV:42-51, 469-488 moved to the device / to worker threads)."""
-    import shutil
-    import tempfile
-    import yaml
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
-    import make_synthetic_dataset as MS
-    from launch import eval_sharded
-    base = tempfile.mkdtemp(prefix="nf_launcher_")
-    try:
-        data = MS.write(os.path.join(base, "data"), size=H, n_train=2, n_val=1, n_test=n_frames)
-        cfg = MS.config(data, os.path.join(base, "logs"))
-        cfg["nerf"]["validation"].update(num_coarse=N_COARSE, num_fine=N_FINE, chunksize=CHUNK)
-        cfg_path = os.path.join(base, "config.yml")
-        with open(cfg_path, "w") as f:
-            yaml.safe_dump(cfg, f)
-        ck_path = os.path.join(base, "ck.ckpt")
-        torch.save({"model_coarse_state_dict": model_c.state_dict(), "model_fine_state_dict": model_f.state_dict(),
-                    "latent_codes": 0.1 * torch.randn(2, 32), "background": None}, ck_path)
-        out = os.path.join(base, "render")
-        eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out, "--save-normals", "--precision", "f32"])
-        st = dict(eval_sharded.main.last_stats)
-        n_png = len([f for f in os.listdir(out) if f.endswith(".png")])
-        assert n_png == n_frames, (n_png, n_frames)
-        return {"launcher_eval_frames_s": st["frames_s"], "launcher_gpu_s_per_frame": st["gpu_s_per_frame"],
-                "launcher_wall_over_gpu": st["wall_s"] / st["gpu_s_total"], "frames": st["frames"], "wall_s": st["wall_s"],
-                "wall_s_until_gpu_idle": st["wall_s_until_gpu_idle"],
-                "what": f"launch/eval_sharded.py, {n_frames} test frames 512x512, 64+128, f32, PNG + normals written, one GPU; wall includes the PNG tail"}
-    finally:
-        shutil.rmtree(base, ignore_errors=True)
-
-
-def pattern_store_probe():
-    """tools/micro/store_bw: the training kernels' store pattern (256 persistent workgroups, 1 KiB per instruction, nine 256 MiB
-    planes = 2.4 GB, nt and default policy) with nothing else in the way -- separates a box whose memory system takes these
-    streams badly from a good one, which the sequential fill probe does not."""
-    exe = os.path.join(ROOT, "tools", "micro", "store_bw")
-    if not os.path.exists(exe):
-        return {"error": "tools/micro/store_bw not built (__graft_entry__.build())"}
-    try:
-        r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
-        return json.loads(r.stdout.strip().splitlines()[-1])
-    except Exception as e:
-        return {"error": repr(e)}
-
-
-def device_info(dev):
-    """What the box reports (re-derive the peaks from the clocks of the GPU box): CUs x 256 fp32-MFMA FLOP per clock x
-    the engine clock, beside the vendor figure the roofline is priced against."""
-    p = torch.cuda.get_device_properties(dev)
-    mhz = float(getattr(p, "clock_rate", 0)) / 1e3
-    if mhz <= 0:                                                        # torch on ROCm reports no clock: ask rocminfo (gfx agent's max clock)
-        try:
-            txt = subprocess.run(["rocminfo"], capture_output=True, text=True, timeout=20).stdout
-            blocks = [b for b in txt.split("*******") if "gfx950" in b and "Max Clock Freq" in b]
-            if blocks:
-                mhz = float(re.search(r"Max Clock Freq\. \(MHz\):\s*(\d+)", blocks[0]).group(1))
-        except Exception:
-            mhz = 0.0
-    cus = int(p.multi_processor_count)
-    # what THIS box's HBM does right now (GPU boxes of the pool differ: one ran every store-heavy kernel 2x slower, profiles/r03_experiments.md §7):
-    # a 1 GiB fill (pure writes) and a 1 GiB copy (read + write) with torch's own kernels, best of 5
-    probe = {}
-    try:
-        x = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-        y = torch.empty_like(x)
-        for name, fn, nbytes in (("hbm_fill_gbs", lambda: x.fill_(1.0), x.numel() * 4), ("hbm_copy_gbs", lambda: y.copy_(x), 2 * x.numel() * 4)):
-            best = 0.0
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn()
-                e1.record()
-                torch.cuda.synchronize()
-                best = max(best, nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9)
-            probe[name] = best
-        del x, y
-        torch.cuda.empty_cache()
-    except Exception as e:
-        probe = {"hbm_probe_error": repr(e)}
-    probe["env"] = {k: v for k, v in os.environ.items() if re.match(r"(HSA|HIP|ROCR|ROCM|GPU|AMD|PYTORCH|NCCL|RCCL)_", k)}   # what differs box to box
-    return {**probe, "name": p.name, "arch": getattr(p, "gcnArchName", ""), "compute_units": cus, "engine_clock_mhz": mhz,
-            "hbm_gib": round(p.total_memory / 2 ** 30, 1),
-            "fp32_mfma_peak_from_clock_tflops": cus * 256 * mhz * 1e6 / 1e12, "fp32_mfma_peak_priced_tflops": PEAK_F32_MFMA_TFLOPS}
-
-
-def _gpu_sysfs(dev):
-    """sysfs directory of the amdgpu device `dev` runs on (None if the container does not show it)."""
-    import glob
-    cards = sorted(d for d in glob.glob("/sys/class/drm/card[0-9]*/device") if os.path.exists(os.path.join(d, "power_dpm_force_performance_level")))
-    if not cards:
-        return None
-    try:                                                             # match by PCI bus id when torch reports it
-        want = torch.cuda.get_device_properties(dev).pci_bus_id
-        for d in cards:
-            if int(os.path.basename(os.path.realpath(d)).split(":")[1], 16) == want:
-                return d
-    except Exception:
-        pass
-    return cards[min(dev.index or 0, len(cards) - 1)]
-
-
-def power_probe(dev, legs, seconds=1.5, period=0.02):
-    """What the board's power management does to each inference kernel on THIS box: socket power, engine / fabric / memory clock read
-    from amdgpu's sysfs nodes every 20 ms while the kernel runs back to back for `seconds`, beside the board's power cap and performance
-    level.  Boxes of the pool differ in how they hold the cap: the builder's lower the engine clock under the 16-bit MFMA kernels
-    (2.1-2.2 GHz), the driver's boxes of rounds 3 and 4 reported 2.38 GHz for every kernel and 1.35x (inference) to 2.9x (training
-    forward) the busy cycles.  Outside every timed region; reads only."""
-    import glob, threading
-    d = _gpu_sysfs(dev)
-    if d is None:
-        return {"error": "no amdgpu sysfs node visible"}
-    hw = (glob.glob(os.path.join(d, "hwmon", "hwmon*")) or [None])[0]
-
-    def rd(path, num=True):
-        try:
-            t = open(path).read().strip()
-            return float(t) if num else t
-        except Exception:
-            return None
-    pwr = next((f for f in ("power1_average", "power1_input") if hw and os.path.exists(os.path.join(hw, f))), None)
-    static = {"sysfs": d, "perf_level": rd(os.path.join(d, "power_dpm_force_performance_level"), False),
-              "power_cap_w": (rd(os.path.join(hw, "power1_cap")) or 0) / 1e6 if hw else None,
-              "power_cap_max_w": (rd(os.path.join(hw, "power1_cap_max")) or 0) / 1e6 if hw else None,
-              "power_node": pwr}
-    for node in ("pp_dpm_sclk", "pp_dpm_fclk", "pp_dpm_mclk", "current_compute_partition", "current_memory_partition"):
-        static[node] = rd(os.path.join(d, node), False)
-
-    def star(node):                                                  # the level amdgpu marks as current in a pp_dpm_* table (MHz)
-        t = rd(os.path.join(d, node), False) or ""
-        m = re.search(r"(\d+)\s*Mhz\s*\*", t, re.I)
-        return float(m.group(1)) if m else None
-    out = {"static": static}
-    for name, fn in legs:
-        fn()
-        torch.cuda.synchronize()
-        rows, stop = [], threading.Event()
-
-        def sample():
-            while not stop.is_set():
-                rows.append((rd(os.path.join(hw, pwr)) if pwr else None, rd(os.path.join(hw, "freq1_input")) if hw else None,
-                             star("pp_dpm_sclk"), star("pp_dpm_fclk"), star("pp_dpm_mclk")))
-                time.sleep(period)
-        th = threading.Thread(target=sample, daemon=True)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        n, t0 = 0, time.perf_counter()
-        th.start()
-        e0.record()
-        while time.perf_counter() - t0 < seconds:
-            fn()
-            n += 1
-            if n % 4 == 0:
-                torch.cuda.synchronize()                             # keep the queue short: the loop ends on time
-        e1.record()
-        torch.cuda.synchronize()
-        stop.set()
-        th.join()
-        rows = rows[len(rows) // 4:]                                  # the first quarter is the ramp
-        mean = lambda k, sc: (sum(r[k] for r in rows if r[k] is not None) / max(1, sum(r[k] is not None for r in rows)) * sc
-                              if any(r[k] is not None for r in rows) else None)
-        out[name] = {"launch_ms": e0.elapsed_time(e1) / n, "launches": n, "samples": len(rows), "power_w": mean(0, 1e-6),
-                     "power_w_max": max((r[0] for r in rows if r[0] is not None), default=0) * 1e-6 if pwr else None,
-                     "sclk_mhz_hwmon": mean(1, 1e-6), "sclk_mhz_dpm": mean(2, 1.0), "fclk_mhz_dpm": mean(3, 1.0), "mclk_mhz_dpm": mean(4, 1.0)}
-    return out
-
-
-def _pmc_guard():
-    """rocprofv3 path, or (None, reason).  Never nest profilers: a PMC pass started from a process that is itself being traced
-    combines counter collection with tracing -- the combination this pool's nodes do not survive."""
-    import shutil
-    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
-    if not os.path.exists(prof):
-        return None, {"error": "rocprofv3 not found"}
-    under = [k for k in os.environ if k.startswith(("ROCPROF", "ROCP_", "ROCTRACER", "ROCPROFILER"))]
-    if under or "rocprof" in os.environ.get("LD_PRELOAD", "").lower():
-        return None, {"skipped": "bench.py is running under a profiler (" + ", ".join(sorted(under)[:4]) + "); PMC passes not nested"}
-    return prof, None
-
-
-def pmc_pass_rows(prof, tmp, counter, script, argv, timeout):
-    """One `rocprofv3 --kernel-trace --pmc <counter>` pass over tools/<script> <argv>: [(kernel_name, grid_x, value, duration_ns
-    or None)] per dispatch, or (None, detail).  The dispatch duration comes from the same pass (the counters view's own
-    start / end stamps when it has them, else the kernel trace joined on the dispatch id)."""
-    import sqlite3
-    out = os.path.join(tmp, counter)
-    env = dict(os.environ, TMPDIR=tmp)
-    env.pop("RANK", None)
-    env.pop("WORLD_SIZE", None)
-    cmd = [prof, "--kernel-trace", "--pmc", counter, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "tools", script), *argv]
-    r = subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
-    dbs = [os.path.join(d, f) for d, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
-    if r.returncode != 0 or not dbs:
-        return None, {"error": f"rocprofv3 pass {counter} failed (rc {r.returncode})", "tail": r.stdout.decode()[-400:]}
-    con = sqlite3.connect(dbs[0])
-    cols = [c[1] for c in con.execute("pragma table_info(counters_collection)").fetchall()]
-    if "start" in cols and "end" in cols:
-        rows = con.execute('select kernel_name, grid_size_x, value, "end" - "start" from counters_collection where counter_name = ?',
-                           (counter,)).fetchall()
-    elif "dispatch_id" in cols:
-        try:
-            kcols = [c[1] for c in con.execute("pragma table_info(kernels)").fetchall()]
-            key = "dispatch_id" if "dispatch_id" in kcols else "id"
-            rows = con.execute(f"select c.kernel_name, c.grid_size_x, c.value, k.duration from counters_collection c left join kernels k "
-                               f"on k.{key} = c.dispatch_id where c.counter_name = ?", (counter,)).fetchall()
-        except Exception:
-            rows = [(n, g, v, None) for n, g, v in con.execute(
-                "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()]
-    else:
-        rows = [(n, g, v, None) for n, g, v in con.execute(
-            "select kernel_name, grid_size_x, value from counters_collection where counter_name = ?", (counter,)).fetchall()]
-    return rows, None
-
-
-def pmc_kernel_bytes(script, argv, kernels, timeout=240):
-    """HBM bytes per launch of the named kernels, measured by THIS command: two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE
-    cannot share a pass on gfx950, MI355X_MICROARCH.md) over tools/<script> <argv>.  Per kernel (substring match, its largest grid):
-    {"fetch_bytes", "write_bytes"}, the counters' KiB x 1024, raw.  Returns (dict or None, detail)."""
-    import shutil
-    import tempfile
-    prof, why = _pmc_guard()
-    if prof is None:
-        return None, why
-    got = {k: {} for k in kernels}
-    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
-    try:
-        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
-            rows, err = pmc_pass_rows(prof, tmp, counter, script, argv, timeout)
-            if rows is None:
-                return None, err
-            for kernel in kernels:
-                hits = [(gx, v) for n, gx, v, _ in rows if kernel in n]
-                big = max((gx for gx, _ in hits), default=None)           # the launch of interest is the kernel's largest grid
-                vals = [v for gx, v in hits if gx == big]
-                if not vals:
-                    return None, {"error": f"kernel {kernel} not found in the {counter} pass", "kernels": sorted({n[:60] for n, _, _, _ in rows})[:8]}
-                got[kernel]["fetch_bytes" if counter == "FETCH_SIZE" else "write_bytes"] = sum(vals) / len(vals) * 1024.0
-        return got, {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE (separate passes) run by bench.py on tools/{script} "
-                               + " ".join(argv) + " in this run"}
-    except Exception as e:
-        return None, {"error": repr(e)}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def pmc_sustained_clock(precision="f32", timeout=240):
-    """The engine clock the headline kernel actually held: GRBM_GUI_ACTIVE (busy cycles of the graphics engine) of its fine-pass launch
-    divided by the duration of the same dispatch, from one rocprofv3 PMC pass over tools/pmc_one_launch.py.  rocprofv3 sums the
-    counter over the 8 XCDs of the device (profiles/r01_mlp_kernels_pmc.md: 18.7e9 'cycles' per second), so a quotient above 6 GHz
-    is divided by the XCD count.  Returns (MHz or None, detail)."""
-    import shutil
-    import tempfile
-    prof, why = _pmc_guard()
-    if prof is None:
-        return None, why
-    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16", "f16x2": "k_paper_mlp_fwd_f16x2"}.get(precision, "k_paper_mlp_fwd<")
-    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
-    try:
-        rows, err = pmc_pass_rows(prof, tmp, "GRBM_GUI_ACTIVE", "pmc_one_launch.py", [precision], timeout)
-        if rows is None:
-            return None, err
-        hits = [(v, d) for n, _, v, d in rows if kernel in n and d]
-        if not hits:
-            return None, {"error": "no dispatch of the kernel with a duration in the GRBM_GUI_ACTIVE pass",
-                          "kernels": sorted({n[:60] for n, _, _, _ in rows})[:8]}
-        per = sorted(v / (d * 1e-9) for v, d in hits)
-        hz = per[len(per) // 2]
-        div = 8 if hz > 6e9 else 1
-        return hz / div / 1e6, {"source": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE run by bench.py on tools/pmc_one_launch.py " + precision,
-                                "kernel": kernel, "dispatches": len(hits), "busy_cycles_raw_median": sorted(v for v, _ in hits)[len(hits) // 2],
-                                "dispatch_ms_under_pmc_median": sorted(d for _, d in hits)[len(hits) // 2] / 1e6, "xcd_sum_divisor": div}
-    except Exception as e:
-        return None, {"error": repr(e)}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
-
-
-def pmc_traffic(precision, timeout=240):
-    """HBM bytes per fine-pass MLP launch of the eval kernel of `precision` (tools/pmc_one_launch.py launches exactly the kernel
-    the roofline object times).  Raw counters, no 2x correction (the dominant reads are 4-byte z loads, not the 16 B/lane stream
-    the guide's correction is calibrated on).  Returns (bytes or None, detail dict)."""
-    kernel = {"bf16x3": "k_paper_mlp_fwd_bf16", "f16x3": "k_paper_mlp_fwd_f16", "f16x2": "k_paper_mlp_fwd_f16x2"}.get(precision, "k_paper_mlp_fwd<")
-    got, detail = pmc_kernel_bytes("pmc_one_launch.py", [precision], [kernel], timeout)
-    if got is None:
-        return None, detail
-    detail.update(got[kernel])
-    return got[kernel]["fetch_bytes"] + got[kernel]["write_bytes"], detail
-
-
-def pmc_train_traffic(train, timeout=300):
-    """Fill `traffic` of every training kernel of the `train` object (all arithmetics in one pair of PMC passes): raw FETCH_SIZE +
-    WRITE_SIZE bytes per launch."""
-    precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
-    names = [k for p in precs for k, _ in TRAIN_KERNELS[p]]
-    got, detail = pmc_kernel_bytes("pmc_train_launch.py", precs, names, timeout)
-    for p in precs:
-        for (kname, _), obj in zip(TRAIN_KERNELS[p], train[p]["roofline"]["kernels"]):
-            if got is None:
-                obj["traffic_detail"] = detail
-                continue
-            f, w = got[kname]["fetch_bytes"], got[kname]["write_bytes"]
-            # `traffic` = the RAW counters (FETCH_SIZE + WRITE_SIZE, KiB x 1024): an independent measurement.  The guide's gfx950 note
-            # (FETCH_SIZE under-counts 16 B/lane reads by 2x) applies to part of these kernels' reads only (the LDS-DMA'd fragment
-            # streams; dZ / d_raw rows are 4 B/lane loads), so the x2 figure is kept beside it as an ESTIMATE of the upper bound, not
-            # as the measurement (ADVICE r04: calibrating the counter against the expected bytes is no measurement)
-            obj["traffic"] = f + w
-            obj["traffic_detail"] = {"fetch_bytes_raw": f, "write_bytes": w, "traffic_if_all_fetches_undercount_2x_estimate": 2 * f + w,
-                                     "algorithmic_bytes_per_launch": obj["algorithmic_hbm_bytes_per_point"] * 2048 * 128, **detail}
-
-
-def pmc_train_clocks(train, timeout=300):
-    """Engine clock each training kernel actually held (GRBM_GUI_ACTIVE / dispatch time, one PMC pass over tools/pmc_train_launch.py in all
-    arithmetics) and its busy cycles: the split kernels (dense 16-bit MFMA + 9 KB/point of HBM traffic) are clocked down by the power
-    management to 1.55-2.1 GHz under sustained load (profiles/r04_experiments.md), so their wall time is cycles / granted clock --
-    `ms_at_nominal_clock` is what the same cycles take at the 2.4 GHz the peaks are quoted at."""
-    import shutil
-    import tempfile
-    precs = [p for p in ("f32", "f16x3", "bf16x3") if p in train and isinstance(train[p].get("roofline"), dict) and "kernels" in train[p]["roofline"]]
-    prof, why = _pmc_guard()
-    if prof is None or not precs:
-        return why
-    tmp = tempfile.mkdtemp(prefix="nf_pmc_")
-    try:
-        rows, err = pmc_pass_rows(prof, tmp, "GRBM_GUI_ACTIVE", "pmc_train_launch.py", precs, timeout)
-        if rows is None:
-            return err
-        for p in precs:
-            for (kname, _), obj in zip(TRAIN_KERNELS[p], train[p]["roofline"]["kernels"]):
-                hits = [(v, d) for n, _, v, d in rows if kname in n and d]
-                if not hits:
-                    continue
-                div = 8 if sorted(v / (d * 1e-9) for v, d in hits)[len(hits) // 2] > 6e9 else 1
-                clk = sorted(v / div / (d * 1e-9) / 1e6 for v, d in hits)
-                cyc = sorted(v / div for v, _ in hits)[len(hits) // 2]
-                obj["sustained_clock_mhz"] = clk[len(clk) // 2]
-                obj["sustained_clock_mhz_range"] = [clk[0], clk[-1]]
-                obj["busy_mcycles"] = cyc / 1e6
-                obj["ms_at_nominal_clock"] = cyc / 2.4e9 * 1e3
-        return {"source": "rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE run by bench.py on tools/pmc_train_launch.py " + " ".join(precs)}
-    except Exception as e:
-        return {"error": repr(e)}
-    finally:
-        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def self_launch(n):

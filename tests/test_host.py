@@ -158,9 +158,9 @@ def test_product_has_no_cpu_path():
 
 
 def test_oracle_is_imported_only_by_the_checkers():
-    """oracle/ is test infrastructure: nothing in the product package, the launchers or tools/ may import it; bench.py may only
-    inside its baseline legs (functions cpu_baseline + its helper _reference_cpu_run, cpu_baseline_tiny, eager_rocm_baseline,
-    eager_rocm_reference) and
+    """oracle/ is test infrastructure: nothing in the product package, the launchers, tools/, bench.py, bench_common.py or bench_probes.py
+    may import it; bench_baselines.py -- the baseline legs of the bench line -- may, and only inside the functions that ARE baselines
+    (cpu_baseline + its helper _reference_cpu_run, cpu_baseline_tiny, eager_rocm_baseline, eager_rocm_reference);
     __graft_entry__ only as the smoke() / build() checker."""
     pat = re.compile(r"^\s*(from\s+oracle\b|import\s+oracle\b)", re.M)
     for base in ("4d-facial-avatars_amd", "tools"):
@@ -169,13 +169,15 @@ def test_oracle_is_imported_only_by_the_checkers():
                 if f.endswith(".py"):
                     src = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(src), os.path.join(dirpath, f)
-    bench = open(os.path.join(ROOT, "bench.py")).read()
+    for f in ("bench.py", "bench_common.py", "bench_probes.py"):
+        assert not pat.search(open(os.path.join(ROOT, f)).read()), f
+    legs_src = open(os.path.join(ROOT, "bench_baselines.py")).read()
     n_legs = 0
     for fn in ("def _reference_cpu_run(", "def cpu_baseline(", "def cpu_baseline_tiny(", "def eager_rocm_baseline(", "def eager_rocm_reference("):
-        leg = bench[bench.index(fn):]
-        leg = leg[:leg.index("\ndef ", 1)]
+        leg = legs_src[legs_src.index(fn):]
+        leg = leg[:leg.index("\ndef ", 1)] if "\ndef " in leg[1:] else leg
         n_legs += len(pat.findall(leg))
-    assert len(pat.findall(bench)) == n_legs > 0
+    assert len(pat.findall(legs_src)) == n_legs > 0
 
 
 def _load_bench():
