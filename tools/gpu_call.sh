@@ -41,7 +41,7 @@ pmc_passes() {   # $1 = output stem, $2 = launch script, $3 = precision, $4 = va
 run_recipe() {
   local r=$1; shift
   case $r in
-    suite) timeout 1500 python -m pytest tests -m gpu -q -x "$@" 2>&1 | grep -v Warning | tail -25 | tee $O/pytest_gpu.txt ;;
+    suite) timeout 1500 python -m pytest tests -m gpu -q -x "$@" > $O/pytest_gpu_full.txt 2>&1; grep -v Warning $O/pytest_gpu_full.txt | tail -25 | tee $O/pytest_gpu.txt ;;
     smoke) timeout 300 python -c "import __graft_entry__ as G; G.smoke()" 2>&1 | tail -3 | tee $O/smoke.txt ;;
     gate)  NERFACE_GATE_MEASURE=1 NERFACE_GATE_JSON=$O/gate timeout 900 python -m pytest tests/test_gpu_gate.py -m gpu -q -s "$@" 2>&1 | grep -E "^\[|passed|failed|Error|assert" | tee $O/gate.txt ;;
     sweep) timeout 900 python tools/frame_gate_sweep.py ${1:-8} $O/gate_sweep.json 2>&1 | tee $O/gate_sweep.txt | tail -12 ;;
