@@ -246,7 +246,7 @@ def test_train_step_f16x3_follows_the_f32_path(hip_lib, gpu, case):
         assert median < 3e-4 and worst < 2e-2 and e_lat < 1e-4 and n_loose <= MAX_LOOSE_TENSORS
 
 
-MAX_LOOSE_TENSORS = 6            # of 48 (two networks x 24 live tensors)
+MAX_LOOSE_TENSORS = 4            # of 48 (two networks x 24 live tensors); measured on MI355X: 2 (the layer of the flipped unit and the one below it)
 
 
 def test_train_step_gradients_vs_oracle_and_reference(hip_lib, gpu):
