@@ -25,7 +25,8 @@ def _reference_cpu_run(n_rays, c, cores):
     """The reference's OWN CPU path on this box's host cores: the unmodified `get_ray_bundle` (H:68-123) for the whole 512x512
     frame plus the unmodified `run_one_iter_of_nerf` (T:165-290) on `n_rays` rays of it, imported from the live tree or from
     oracle/_ref/nerface_ref.zip (oracle/make_ref.py packs the untouched files; the archive travels with the push).  Returns
-    (outputs, seconds of run_one_iter_of_nerf on the sample, seconds of the full-frame get_ray_bundle, threads, kind string)."""
+    (outputs, seconds of run_one_iter_of_nerf on the sample, seconds of the full-frame get_ray_bundle, threads, kind string, the
+    thread-count calibration table)."""
     from oracle import make_golden as MG
     from oracle import nerface_oracle as O
     from oracle import ref_import as RI
@@ -51,7 +52,7 @@ def _reference_cpu_run(n_rays, c, cores):
                 best, best_t = nt, t
             if t > 4.0 * best_t:                                            # far off the best: larger counts will not recover
                 break
-        _reference_cpu_run.calibration = {"rays": n_cal, "rays_per_s_by_threads": table}
+        calibration = {"rays": n_cal, "rays_per_s_by_threads": table}
         torch.set_num_threads(best)
         pose = O.frame_pose(c["frame"])[:3, :4]
         ref.get_ray_bundle(H, W, INTRINSICS, pose)
@@ -61,7 +62,7 @@ def _reference_cpu_run(n_rays, c, cores):
         t0 = time.perf_counter()
         out, _ = MG.run_reference(ref, c)
         dt = time.perf_counter() - t0
-    return out, dt, t_bundle, best, RI.reference_kind()
+    return out, dt, t_bundle, best, RI.reference_kind(), calibration
 
 
 def cpu_baseline(n_rays=12288):
@@ -81,11 +82,11 @@ def cpu_baseline(n_rays=12288):
     kind, ref_detail, port_detail = "port", None, None
     if RI.reference_importable():
         try:
-            ref, dt, t_bundle, best, how = _reference_cpu_run(n_rays, c, cores)
+            ref, dt, t_bundle, best, how, calibration = _reference_cpu_run(n_rays, c, cores)
             kind = "reference"
             t_total = dt + t_bundle * n_rays / float(H * W)                # the frame's ray bundle, charged per ray
             ref_detail = {"run_one_iter_of_nerf_s": dt, "get_ray_bundle_full_frame_s": t_bundle, "imported_from": how,
-                          "thread_calibration": getattr(_reference_cpu_run, "calibration", None)}
+                          "thread_calibration": calibration}
             # the oracle port on a slice of the same rays, same threads: how close the restatement's speed is to the real thing
             n_port = min(n_rays, 2048)
             cp = dict(c)
