@@ -80,14 +80,17 @@ def test_train_then_eval_roundtrip(hip_lib, gpu, tmp_path):
     eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out2, "--precision", "bf16x3"])
     b = np.asarray(Image.open(os.path.join(out2, "0001.png")))
     assert a.shape == b.shape                      # (perturb=True in validation, as shipped: images differ by sampling noise)
+    # round 6: bf16x3 / f16x2 do not keep the 1e-4 dB gate against realistic targets on every scene, so the launcher verifies them by
+    # default (every 50th frame of a rank, i.e. frame 0 here, also on the exact-f32 kernels) -- f16x3 and f32 are not verified
+    assert eval_sharded.main.last_stats["gate"]["frames"] == 1 and eval_sharded.main.last_stats["gate"]["precision"] == "bf16x3"
     out3 = os.path.join(base, "render_h")          # split-fp16: pre-flight range probe + sticky range flag run inside the launcher
     assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out3, "--precision", "f16x3"]) == [0, 1, 2]
     h = np.asarray(Image.open(os.path.join(out3, "0001.png")))
-    assert h.shape == a.shape and h.std() > 0
+    assert h.shape == a.shape and h.std() > 0 and "gate" not in eval_sharded.main.last_stats
     out4 = os.path.join(base, "render_x2")         # "f16x2" (two products per weight): same probe and flag, inference-only arithmetic
     assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out4, "--precision", "f16x2"]) == [0, 1, 2]
     x2 = np.asarray(Image.open(os.path.join(out4, "0001.png")))
-    assert x2.shape == a.shape and x2.std() > 0
+    assert x2.shape == a.shape and x2.std() > 0 and eval_sharded.main.last_stats["gate"]["frames"] == 1
     out5 = os.path.join(base, "render_x2_verified")  # --verify-gate: every frame also on the exact-f32 kernels, same draws; the gate is REPORTED
     assert eval_sharded.main(["--config", cfg_path, "--checkpoint", ck_path, "--savedir", out5, "--precision", "f16x2", "--verify-gate", "1"]) == [0, 1, 2]
     gate = eval_sharded.main.last_stats["gate"]
