@@ -51,7 +51,7 @@ static void nf_build_table_bf16(std::vector<uint32_t>& t) {
                             case 4: c = code(8, n, hid_feature(s, h, j), 256); break;
                             case 5: c = code(10, n, hid_feature(s, h, j), 256); break;
                             case 6: c = code(12, n, hid_feature(s, h, j), 256); break;
-                            case 7: {   // layers_dir.0 (+ fc_alpha as row 128); k-steps 0..15 feat, 16 dir slots, 17..19 zero
+                            case 7: {   // layers_dir.0 (+ fc_alpha as row 128); k-steps 0..15 feat, 16 dir slots, 17 zero
                                 if (n < 128) {
                                     if (s < 16) c = code(16, n, hid_feature(s, h, j), 280);
                                     else if (s == 16) { const int col = dir_col(h, j); if (col >= 0) c = code(16, n, col, 280); }

@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 namespace nfb {
 // layer table of the bf16 stream: k-steps (16 slots each, always even) and 32-row output tiles
 constexpr int NL = 11;
-constexpr int KS[NL] = {4, 16, 16, 20, 16, 16, 16, 20, 8, 8, 8};   // multiples of the stage depth (4 k-steps)
+constexpr int KS[NL] = {4, 16, 16, 20, 16, 16, 16, 18, 8, 8, 8};   // multiples of the stage depth (2 k-steps); layers_dir.0: 16 feat + dir + ONE zero k-step (round 5: 3)
 constexpr int NO[NL] = {8, 8, 8, 8, 8, 8, 8, 5, 4, 4, 1};
 constexpr int pair_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += KS[i] * NO[i]; return o; }
 constexpr int N_PAIRS = pair_off(NL);                 // (hi, lo) 1-KiB block pairs

@@ -6,7 +6,7 @@
 //        W.x ~= W_hi.x_hi + W_lo.x_hi               (weights keep both halves: 22 bits), f32 accumulation
 //
 // Same kernel body, weight stream (nf_paper_pack_f16: the packed image of "f16x3" is used as it is), LDS ring, scales and range guard
-// as nf_mlp_f16.hip; the W_hi.x_lo MFMAs and the conversions that feed them are not issued: 2008 instead of 3012 MFMAs per 32 points.
+// as nf_mlp_f16.hip; the W_hi.x_lo MFMAs and the conversions that feed them are not issued: 1988 instead of 2982 MFMAs per 32 points.
 // Why THIS term (profiles/r05_split_products.md, nine variants measured on MI355X): rounding an ACTIVATION is an error that differs
 // from point to point and averages out over a ray and over the image (whole 512 x 512 frames: |dPSNR| 2e-6 .. 5.6e-5 dB
 // over 21 frames -- median 9e-6 on the bench scene's x1000 density head, 5e-6 on the x40 head; self-PSNR 60 .. 115 dB), rounding a WEIGHT is the same error at every point --

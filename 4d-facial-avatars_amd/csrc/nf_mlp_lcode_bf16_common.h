@@ -22,7 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace nfb {
 constexpr int NL = 8;
-constexpr int KS[NL] = {4, 16, 16, 16, 16, 16, 20, 8};
+constexpr int KS[NL] = {4, 16, 16, 16, 16, 16, 18, 8};   // layers_dir.0: 16 feat k-steps + the dir k-step + ONE zero k-step (a stage is 2 k-steps; round 5: 3)
 constexpr int NO[NL] = {8, 8, 8, 8, 1, 8, 4, 1};
 constexpr int pair_off(int l) { int o = 0; for (int i = 0; i < l; ++i) o += KS[i] * NO[i]; return o; }
 constexpr int N_PAIRS = pair_off(NL);

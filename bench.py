@@ -622,7 +622,7 @@ def main():
         for prec, kname, peak_name in (("bf16x3", "k_paper_mlp_fwd_bf16", "bf16"), ("f16x3", "k_paper_mlp_fwd_f16", "fp16"),
                                        ("f16x2", "k_paper_mlp_fwd_f16x2", "fp16")):
             ach = flops / (ms[prec] * 1e-3) / 1e12
-            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT * (2008.0 / 3012.0 if prec == "f16x2" else 1.0) / (ms[prec] * 1e-3) / 1e12
+            exe = float(CHUNK) * S * BF16X3_EXEC_FLOP_PER_POINT * (SPLIT_MFMAS_PER_TILE["x2"] / float(SPLIT_MFMAS_PER_TILE["x3"]) if prec == "f16x2" else 1.0) / (ms[prec] * 1e-3) / 1e12
             objs[prec] = {"bound": "mfma", "kernel": f"{kname} (65536 rays x 192 samples per launch)",
                           "achieved": ach, "peak": PEAK_BF16_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_MFMA_TFLOPS,
                           "avg_launch_ms": ms[prec], "algorithmic_flops_per_launch": flops, "algorithmic_hbm_bytes_per_launch": algo_bytes,

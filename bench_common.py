@@ -26,7 +26,8 @@ DW_FLOP_PER_POINT = 1_100_032         # weight gradients: one outer product per 
 PEAK_F32_MFMA_TFLOPS = 157.3          # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
 PEAK_HBM_GBS = 8000.0                 # MI355X HBM3E spec peak (MI355X_MICROARCH.md; about 6.3 TB/s is achievable)
 PEAK_BF16_MFMA_TFLOPS = 2500.0        # MI355X dense bf16 MFMA (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
-BF16X3_EXEC_FLOP_PER_POINT = 3012 * 32768 / 32   # executed MFMA FLOPs per point of the split-bf16 kernel (3012 MFMAs / 32 points)
+SPLIT_MFMAS_PER_TILE = {"x3": 2982, "x2": 1988}   # v_mfma_f32_32x32x16 per 32-point wave tile of the split inference kernels (round 5: 3012 / 2008)
+BF16X3_EXEC_FLOP_PER_POINT = SPLIT_MFMAS_PER_TILE["x3"] * 32768 / 32   # executed MFMA FLOPs per point of the three-product kernels
 INTRINSICS = np.array([-1481.96352, 1559.67488, 0.565694, 0.413902])
 NEAR, FAR = 0.2, 0.8
 CPU_CALIBRATION_RAYS = 4096           # slice of the CPU sample on which the thread count of the reference's CPU run is chosen
@@ -43,9 +44,9 @@ TRAIN_KERNELS = {
 TRAIN_BYTES_PER_POINT = (4 * (2256 + 72) + 4 + 16, 4 * 72 + 16 + 4 * 2176, 4 * (2256 + 2176 + 4))
 TRAIN_FLOP_PER_POINT = (FLOP_PER_POINT, CHAIN_FLOP_PER_POINT, DW_FLOP_PER_POINT)
 # issued 16-bit MFMA FLOPs per point of the split training kernels: v_mfma_f32_32x32x16 = 32768 FLOPs per 32 points; the forward with
-# saves issues 3284 per wave tile (3012 + 272 transposing ones), the dX chain 2760 (static counts of the ISA, tools/isa_summary.py),
+# saves issues 3254 per wave tile (2982 + 272 transposing ones), the dX chain 2760 (static counts of the ISA, tools/isa_summary.py),
 # the weight-gradient GEMMs three products per algorithmic one
-TRAIN_SPLIT_EXEC_FLOP_PER_POINT = (3284 * 1024, 2760 * 1024, 3 * DW_FLOP_PER_POINT)
+TRAIN_SPLIT_EXEC_FLOP_PER_POINT = (3254 * 1024, 2760 * 1024, 3 * DW_FLOP_PER_POINT)
 # (lcode family, --mode train --family lcode: whole-iteration bytes only)
 LCODE_BYTES_PER_POINT = {"f32": 4 * 1488 + (4 * (4 * 256 + 128) + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
                          "bf16x3": 4 * 1528 + (40 + 16) + 4 * 1408 + 4 * (1488 + 1408 + 4),
