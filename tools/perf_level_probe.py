@@ -1,5 +1,5 @@
 """Launch time, socket power and engine clock of the inference kernels and the split training forward under the box's CURRENT power-management
-settings (bench.power_probe: each kernel back to back for 1.5 s, sysfs sampled every 20 ms).  Run by tools/gpu_calls/r05_c13.sh under
+settings (bench.power_probe: each kernel back to back for 1.5 s, sysfs sampled every 20 ms).  Run in round 5 (call 13; now: bash tools/gpu_call.sh TAG py tools/perf_level_probe.py) under
 `auto`, a forced `high` performance level and a lowered power cap: which setting produces the driver-box signature of rounds 3-4 (16-bit MFMA
 kernels slower at a HIGHER reported clock)?"""
 import os, sys
