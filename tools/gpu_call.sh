@@ -12,6 +12,7 @@
 #   pmctrain <prec> [variant]  the same passes over tools/pmc_train_launch.py <prec>   -> pmc_train_<prec>[_variant].md
 #   bench [bench.py args]      python bench.py ...                                     -> bench_line.json (last line), bench.log
 #   stats [bench.py args]      rocprofv3 --kernel-trace --stats of bench.py --no-extras --no-cpu-baseline ... -> kernel_stats.md
+#   abpy <variant> <script> [args]  python <script> ... on the default library and on the variant, outputs side by side -> <script>_{default,variant}.txt
 #   py <script> [args]         python <script> ... (cwd = repo root)                   -> <script basename>.txt
 cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
 ROOT=$PWD
@@ -55,6 +56,10 @@ run_recipe() {
     bench) timeout 1500 python bench.py "$@" > $O/bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench.log > $O/bench_line.json; cp gpurun_out/bench_detail.json $O/ 2>/dev/null; tail -c 2500 $O/bench_line.json ;;
     stats) rm -rf /tmp/stats; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/stats -o s -- python $ROOT/bench.py --no-extras --no-cpu-baseline "$@" > $O/stats.log 2>&1 ); echo "stats rc=$?"
            python tools/rocpd_summary.py stats $(find /tmp/stats -name '*.db' | head -1) > $O/kernel_stats.md 2>&1; head -14 $O/kernel_stats.md | cut -c1-150 ;;
+    abpy)  local v=$1 s=$2; shift 2; local b=$(basename $s .py)
+           timeout 600 python "$s" "$@" > $O/${b}_default.txt 2>&1
+           NERFACE_HIP_LIB=$L/libnerface_hip_$v.so timeout 600 python "$s" "$@" > $O/${b}_$v.txt 2>&1
+           echo "== $s: default | $v"; paste -d'|' <(grep -v Warning $O/${b}_default.txt | cut -c1-110) <(grep -v Warning $O/${b}_$v.txt | cut -c1-110) | tail -14 ;;
     py)    local s=$1; shift; timeout 900 python "$s" "$@" 2>&1 | tee $O/$(basename $s .py).txt | tail -40 ;;
     *) echo "unknown recipe $r"; return 2 ;;
   esac
