@@ -459,7 +459,8 @@ def main():
                                              expressions=conds[i][0], background_prior=background, latent_code=conds[i][1])
 
     def timed_frames():
-        """W warm-up frames, then exactly K frames between barrier + synchronize on both sides; max over ranks."""
+        """W warm-up frames, then exactly K frames between barrier + synchronize on both sides.  Returns (seconds of the slowest rank,
+        [ms per step of every rank])."""
         for i in range(args.warmup):
             out = step(i)
         torch.cuda.synchronize()
@@ -470,23 +471,23 @@ def main():
         for i in range(args.warmup, n_frames):
             out = step(i)
         torch.cuda.synchronize()
+        own = time.perf_counter() - t0                                       # this rank's own K frames, before it waits for the others
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")   # (gloo gathers host tensors only)
+            t = torch.tensor([dt, own], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")   # (gloo gathers host tensors only)
             per = [torch.zeros_like(t) for _ in range(world)]
-            dist.all_gather(per, t)                                          # every rank's own time: stragglers show on the line
-            timed_frames.per_rank_ms = [1e3 * float(x.item()) / max(args.steps, 1) for x in per]
-            dt = max(float(x.item()) for x in per)                           # the job's time = the slowest rank's
+            dist.all_gather(per, t)
+            per_rank = [1e3 * float(x[1].item()) / max(args.steps, 1) for x in per]    # every rank's own time: stragglers show on the line
+            dt = max(float(x[0].item()) for x in per)                        # the job's time = the slowest rank's, closing barrier included
         else:
-            timed_frames.per_rank_ms = [1e3 * dt / max(args.steps, 1)]
+            per_rank = [1e3 * own / max(args.steps, 1)]
         assert out[3].shape == (H, W, 3) and bool(torch.isfinite(out[3]).all())
-        return dt
+        return dt, per_rank
 
-    dt = timed_frames()
-    per_rank_ms = list(timed_frames.per_rank_ms)
+    dt, per_rank_ms = timed_frames()
     rays_total = world * args.steps * H * W
     # what each arithmetic is, and which targets it keeps north_star's 1e-4 dB gate against (profiles/r06_gate_sensitivity.md, nerf.gate.EXPECTED_PASS)
     dtype_of = {"f32": "f32",
@@ -511,7 +512,7 @@ def main():
     if not args.no_extras:
         for other in others:
             nerf.set_mlp_precision(other)
-            dt_o = timed_frames()
+            dt_o, _ = timed_frames()
             line[key_of[other]] = {
                 "value": rays_total / dt_o, "unit": "rays/s", "ms_per_step": 1e3 * dt_o / max(args.steps, 1), "steps": args.steps,
                 "warmup": args.warmup, "dtype": dtype_of[other],

@@ -199,7 +199,7 @@ def test_bench_bare_gpus_2_launches_its_own_ranks(hip_lib, gpu):
     assert r.returncode != 0 and b"must agree" in r.stderr
     # per-rank step times on the line: stragglers show
     assert len(d["per_rank_ms_per_step"]) == 2 and c["summary"]["rank_ms_max"] >= c["summary"]["rank_ms_min"] > 0
-    assert abs(c["summary"]["rank_ms_max"] - c["ms_per_step"]) <= 1e-3 * c["ms_per_step"]        # the job's time is the slowest rank's
+    assert c["summary"]["rank_ms_max"] <= c["ms_per_step"] * (1 + 1e-6)           # a rank's own frames, measured before the closing barrier
 
 
 def test_bench_more_ranks_than_devices_fails_fast_with_the_reason(hip_lib, gpu):
