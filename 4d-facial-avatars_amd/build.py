@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc")
 OUT_DIR = os.path.join(HERE, "lib")
 OUT = os.path.join(OUT_DIR, "libnerface_hip.so")
-SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_choice.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_mlp_bf16.hip", "nf_mlp_f16.hip", "nf_mlp_f16x2.hip", "nf_mlp_f16_train.hip", "nf_mlp_f16_bwd.hip", "nf_mlp_f16_dw.hip", "nf_mlp_bf16_train.hip", "nf_mlp_bf16_bwd.hip", "nf_mlp_bf16_dw.hip", "nf_tiny.hip", "nf_mlp_lcode.hip", "nf_mlp_lcode_bwd.hip", "nf_mlp_lcode_bf16.hip", "nf_mlp_lcode_f16.hip", "nf_mlp_lcode_f16x2.hip", "nf_mlp_lcode_f16_train.hip", "nf_mlp_lcode_f16_bwd.hip", "nf_mlp_lcode_bf16_train.hip", "nf_mlp_lcode_bf16_bwd.hip", "nf_pipeline.hip", "nf_mlp_encoded.hip", "nf_optim.hip"]
+SOURCES = ["nf_lib.hip", "nf_rays.hip", "nf_choice.hip", "nf_render.hip", "nf_mlp.hip", "nf_mlp_bwd.hip", "nf_mlp_bf16.hip", "nf_mlp_f16.hip", "nf_mlp_f16x2.hip", "nf_mlp_f16_train.hip", "nf_mlp_f16_bwd.hip", "nf_mlp_f16_dw.hip", "nf_mlp_bf16_train.hip", "nf_mlp_bf16_bwd.hip", "nf_mlp_bf16_dw.hip", "nf_tiny.hip", "nf_flex.hip", "nf_mlp_lcode.hip", "nf_mlp_lcode_bwd.hip", "nf_mlp_lcode_bf16.hip", "nf_mlp_lcode_f16.hip", "nf_mlp_lcode_f16x2.hip", "nf_mlp_lcode_f16_train.hip", "nf_mlp_lcode_f16_bwd.hip", "nf_mlp_lcode_bf16_train.hip", "nf_mlp_lcode_bf16_bwd.hip", "nf_pipeline.hip", "nf_mlp_encoded.hip", "nf_optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-fvisibility=default",
          "-Wno-unused-result"]
 

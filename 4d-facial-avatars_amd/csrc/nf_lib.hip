@@ -1,7 +1,7 @@
 // Library-level entry points of libnerface_hip.so.
 #include "nf_common.h"
 
-extern "C" int nf_abi_version(void) { return 4; }
+extern "C" int nf_abi_version(void) { return 5; }
 
 extern "C" const char* nf_error_string(int code) {
     if (code == 0) return "ok";

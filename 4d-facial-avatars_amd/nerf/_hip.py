@@ -112,6 +112,17 @@ _PROTOTYPES = {
     "nf_tiny_bwd_workspace_floats": (_Z, [_L]),
     "nf_tiny_mlp_bwd": (C.c_int, [_P, _P, _P, _L, _I, _P, _Z, _P, _P]),
     "nf_selftest_dw_tables_tiny": (C.c_int, []),
+    "nf_flex_packed_floats": (_Z, [_I]),
+    "nf_flex_pack": (C.c_int, [_I, _P, _P, _P]),
+    "nf_flex_mlp_fwd": (C.c_int, [_I, _P, _P, _P, _P, _I, _L, _I, _P, _P]),
+    "nf_flex_saved_floats": (_Z, [_I, _L]),
+    "nf_flex_mlp_fwd_train": (C.c_int, [_I, _P, _P, _P, _P, _I, _L, _I, _P, _P, _P]),
+    "nf_flex_packed_bwd_floats": (_Z, [_I]),
+    "nf_flex_pack_bwd": (C.c_int, [_I, _P, _P, _P]),
+    "nf_flex_grad_floats": (_Z, [_I]),
+    "nf_flex_bwd_workspace_floats": (_Z, [_I, _L]),
+    "nf_flex_mlp_bwd": (C.c_int, [_I, _P, _P, _P, _L, _I, _P, _Z, _P, _P]),
+    "nf_selftest_dw_tables_flex": (C.c_int, [_I]),
     "nf_volume_render_fwd": (C.c_int, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, _P]),
     "nf_volume_render_bwd": (C.c_int, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "nf_sample_pdf": (C.c_int, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
@@ -130,7 +141,7 @@ _PROTOTYPES = {
 _OPTIONAL = set()
 # the revision of include/nerface_hip.h these prototypes were written for (nf_abi_version() of the library must equal it: a stale
 # .so with other signatures would take e.g. a stream pointer as `saved_f32` without any error)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def lib_path() -> str:

@@ -384,3 +384,60 @@ class ConditionalBlendshapeLearnableCodeNeRFModel(torch.nn.Module):
             H.check(lib.nf_lcode_forward_encoded(H.ptr(packed), H.ptr(x), H.ptr(expr_d), H.ptr(lat_d), x.shape[0], H.ptr(cond),
                                                  H.ptr(out), H.stream_ptr(dev)), "nf_lcode_forward_encoded")
         return out
+
+
+class FlexibleNeRFModel(torch.nn.Module):
+    r"""Reference nerf/models.py:351-422: constructor signature, parameter names, shapes and default initialisation as there, so
+    its state_dicts load unchanged.
+
+    The HIP path is built for the configuration that reads BASELINE config 1 literally ("tiny_nerf ... 4-layer MLP"):
+    `FlexibleNeRFModel(num_layers=L, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True, use_viewdirs=False)` with
+    L = 2 .. 5 (no skip connection fires below 6 layers, M:373 / 404-409):
+    PE10(xyz) (63) -> layer1 (Linear 128, NO activation, M:402) -> (L - 1) x (Linear 128 + ReLU) -> fc_out (Linear 4).
+    It is evaluated inside the fused tiny-path kernels (`tiny_nerf.run_one_iter_of_tinynerf(..., model, 10)`: nf_flex_mlp_fwd and, with
+    gradients enabled, nf_flex_mlp_fwd_train / nf_flex_mlp_bwd); other geometries construct and load but have no kernel and raise."""
+
+    def __init__(self, num_layers=4, hidden_size=128, skip_connect_every=4, num_encoding_fn_xyz=6, num_encoding_fn_dir=4,
+                 include_input_xyz=True, include_input_dir=True, use_viewdirs=True):
+        super().__init__()
+        include_input_xyz = 3 if include_input_xyz else 0
+        include_input_dir = 3 if include_input_dir else 0
+        self.dim_xyz = include_input_xyz + 2 * 3 * num_encoding_fn_xyz
+        self.dim_dir = include_input_dir + 2 * 3 * num_encoding_fn_dir
+        self.skip_connect_every = skip_connect_every
+        if not use_viewdirs:
+            self.dim_dir = 0
+        self.layer1 = torch.nn.Linear(self.dim_xyz, hidden_size)
+        self.layers_xyz = torch.nn.ModuleList()
+        for i in range(num_layers - 1):
+            skip = i % self.skip_connect_every == 0 and i > 0 and i != num_layers - 1                                  # M:373
+            self.layers_xyz.append(torch.nn.Linear(self.dim_xyz + hidden_size if skip else hidden_size, hidden_size))
+        self.use_viewdirs = use_viewdirs
+        if self.use_viewdirs:
+            self.layers_dir = torch.nn.ModuleList()
+            self.layers_dir.append(torch.nn.Linear(self.dim_dir + hidden_size, hidden_size // 2))
+            self.fc_alpha = torch.nn.Linear(hidden_size, 1)
+            self.fc_rgb = torch.nn.Linear(hidden_size // 2, 3)
+            self.fc_feat = torch.nn.Linear(hidden_size, hidden_size)
+        else:
+            self.fc_out = torch.nn.Linear(hidden_size, 4)
+        self.relu = torch.nn.functional.relu
+
+    @property
+    def num_layers(self) -> int:
+        return len(self.layers_xyz) + 1
+
+    def fused_supported(self) -> bool:
+        return (not self.use_viewdirs and self.dim_xyz == 63 and self.layer1.out_features == 128 and 2 <= self.num_layers <= 5
+                and all(l.in_features == 128 for l in self.layers_xyz))
+
+    def hip_param_list(self):
+        """state_dict order: layer1, layers_xyz.0 .. , fc_out (weight, bias each) -- the order of nf_flex_pack / nf_flex_mlp_bwd."""
+        ps = [self.layer1.weight, self.layer1.bias]
+        for l in self.layers_xyz:
+            ps += [l.weight, l.bias]
+        return ps + [self.fc_out.weight, self.fc_out.bias]
+
+    def forward(self, x):
+        raise NotImplementedError("FlexibleNeRFModel is evaluated inside the fused tiny-path kernel: call "
+                                  "tiny_nerf.run_one_iter_of_tinynerf(..., model, 10)")

@@ -6,6 +6,11 @@ The forward pass (what TN:111-159 computes) is one fused HIP kernel for query po
 3-layer MLP (nf_tiny_mlp_fwd) and one for the compositing (nf_render_volume_density).  With gradients enabled the same
 call is differentiable w.r.t. the six model parameters (the reference script is a trainer, TN:282-302): the training
 forward saves PE / h1 / h2, and the backward runs nf_render_volume_density_bwd + nf_tiny_mlp_bwd (exact f32).
+
+BASELINE config 1 says "4-layer MLP"; the script's own model has three Linear layers.  Both readings run: `model` may also be the
+reference's `nerf.models.FlexibleNeRFModel(num_layers=4, hidden_size=128, num_encoding_fn_xyz=10, use_viewdirs=False)` (M:351-422;
+2 .. 5 layers), which the reference's run_one_iter_of_tinynerf accepts as it accepts any module mapping (N, 63) to (N, 4) -- the
+nf_flex_* kernels, forward and backward.
 """
 from __future__ import annotations
 
@@ -16,6 +21,7 @@ import torch
 
 from nerf import _hip as H
 from nerf import get_minibatches, get_ray_bundle, positional_encoding  # noqa: F401  (same imports as the reference script)
+from nerf.models import FlexibleNeRFModel
 from nerf.ops import _c, bump_pack_epoch, pack_epoch
 
 
@@ -52,6 +58,43 @@ def render_volume_density(radiance_field, ray_origins, depth_values):
     return rgb.reshape(*lead, 3), dmap.reshape(lead), acc.reshape(lead)
 
 
+def _api(model):
+    """(entry-point prefix, leading arguments) of the kernels built for `model`: nf_tiny_* for VeryTinyNerfModel(128, 10),
+    nf_flex_*(num_layers, ...) for FlexibleNeRFModel(L, 128, num_encoding_fn_xyz=10, use_viewdirs=False)."""
+    if isinstance(model, VeryTinyNerfModel) and model.fused_supported():
+        return "nf_tiny", ()
+    if isinstance(model, FlexibleNeRFModel) and model.fused_supported():
+        return "nf_flex", (model.num_layers,)
+    raise NotImplementedError("the fused tiny kernels are built for VeryTinyNerfModel(128, num_encoding_functions=10) and "
+                              "FlexibleNeRFModel(num_layers=2..5, hidden_size=128, num_encoding_fn_xyz=10, use_viewdirs=False)")
+
+
+def _fn(model, name):
+    """The C entry point `<prefix>_<name>` of the model's kernel family with the family's leading arguments bound."""
+    prefix, lead = _api(model)
+    f = getattr(H.lib(), f"{prefix}_{name}")
+    return lambda *args: f(*lead, *args)
+
+
+def _image(model, kind):
+    """Fragment-ordered weight image of a tiny-path model (kind "pack": forward, "pack_bwd": transposed, for the backward chain),
+    rebuilt when a parameter's storage / version counter or the pack epoch moves (fused optimizers do not bump version counters)."""
+    ps = model.hip_param_list()
+    sig = (pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
+    cache = model.__dict__.setdefault("_tiny_images", {})
+    hit = cache.get(kind)
+    if hit is None or hit[0] != sig:
+        dev = H.require_device(*[p.detach() for p in ps])
+        size = _fn(model, "packed_floats" if kind == "pack" else "packed_bwd_floats")()
+        img = torch.empty(size, dtype=torch.float32, device=dev)
+        arr = (C.c_void_p * len(ps))(*[int(p.data_ptr()) for p in ps])
+        with torch.cuda.device(dev):
+            H.check(_fn(model, kind)(arr, H.ptr(img), H.stream_ptr(dev)), f"{_api(model)[0]}_{kind}")
+        cache[kind] = (sig, img)
+        hit = cache[kind]
+    return hit[1]
+
+
 class VeryTinyNerfModel(torch.nn.Module):
     """TN:162-181: three Linear layers, 3 + 6 n -> filter -> filter -> 4.  The HIP kernel is built for the reference's
     configuration (filter_size=128, num_encoding_functions=10 as at TN:264-276)."""
@@ -62,46 +105,28 @@ class VeryTinyNerfModel(torch.nn.Module):
         self.layer2 = torch.nn.Linear(filter_size, filter_size)
         self.layer3 = torch.nn.Linear(filter_size, 4)
         self.relu = torch.nn.functional.relu
-        self._packed = None
-        self._sig = None
 
     def fused_supported(self):
         return self.layer1.in_features == 63 and self.layer1.out_features == 128
 
+    def hip_param_list(self):
+        return [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
+
     def hip_packed(self):
-        ps = [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
-        sig = (pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if self._packed is None or sig != self._sig:
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed = torch.empty(lib.nf_tiny_packed_floats(), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * 6)(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_tiny_pack(arr, H.ptr(self._packed), H.stream_ptr(dev)), "nf_tiny_pack")
-            self._sig = sig
-        return self._packed
+        return _image(self, "pack")
 
     def hip_packed_t(self):
         """Transposed fragment image of layer2 / layer3 for the backward chain (cached like hip_packed)."""
-        ps = [self.layer1.weight, self.layer1.bias, self.layer2.weight, self.layer2.bias, self.layer3.weight, self.layer3.bias]
-        sig = (pack_epoch(),) + tuple((int(p.data_ptr()), int(p._version)) for p in ps)
-        if getattr(self, "_packed_t", None) is None or sig != getattr(self, "_sig_t", None):
-            dev = H.require_device(*[p.detach() for p in ps])
-            lib = H.lib()
-            self._packed_t = torch.empty(lib.nf_tiny_packed_bwd_floats(), dtype=torch.float32, device=dev)
-            arr = (C.c_void_p * 6)(*[int(p.data_ptr()) for p in ps])
-            with torch.cuda.device(dev):
-                H.check(lib.nf_tiny_pack_bwd(arr, H.ptr(self._packed_t), H.stream_ptr(dev)), "nf_tiny_pack_bwd")
-            self._sig_t = sig
-        return self._packed_t
+        return _image(self, "pack_bwd")
 
     def forward(self, x):
         raise NotImplementedError("VeryTinyNerfModel is evaluated inside the fused kernel: call run_one_iter_of_tinynerf(...)")
 
 
 class _TinyRender(torch.autograd.Function):
-    """rgb (n_rays, 3) = render_volume_density(VeryTinyNerfModel(PE(ro + rd * depth))) with gradients for the six parameters
-    (TN:111-159 under autograd).  Ray origins / directions / depths carry no gradient (nothing upstream is learnable)."""
+    """rgb (n_rays, 3) = render_volume_density(model(PE(ro + rd * depth))) with gradients for the model's parameters
+    (TN:111-159 under autograd; model: VeryTinyNerfModel or FlexibleNeRFModel, `params` = model.hip_param_list()).  Ray origins /
+    directions / depths carry no gradient (nothing upstream is learnable)."""
 
     @staticmethod
     def forward(ctx, model, ro, rd, depth, n_samples, *params):
@@ -109,13 +134,13 @@ class _TinyRender(torch.autograd.Function):
         n = ro.shape[0]
         lib = H.lib()
         raw = torch.empty((n, n_samples, 4), dtype=torch.float32, device=dev)
-        saved = torch.empty(lib.nf_tiny_saved_floats(n * n_samples), dtype=torch.float32, device=dev)
+        saved = torch.empty(_fn(model, "saved_floats")(n * n_samples), dtype=torch.float32, device=dev)
         rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
         dmap = torch.empty((n,), dtype=torch.float32, device=dev)
         acc = torch.empty((n,), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
-            H.check(lib.nf_tiny_mlp_fwd_train(H.ptr(model.hip_packed()), H.ptr(ro), H.ptr(rd), H.ptr(depth), 1, n, n_samples, H.ptr(raw),
-                                              H.ptr(saved), H.stream_ptr(dev)), "nf_tiny_mlp_fwd_train")
+            H.check(_fn(model, "mlp_fwd_train")(H.ptr(_image(model, "pack")), H.ptr(ro), H.ptr(rd), H.ptr(depth), 1, n, n_samples, H.ptr(raw),
+                                                H.ptr(saved), H.stream_ptr(dev)), "mlp_fwd_train")
             H.check(lib.nf_render_volume_density(H.ptr(raw), H.ptr(depth), n, n_samples, H.ptr(rgb), H.ptr(dmap), H.ptr(acc),
                                                  H.stream_ptr(dev)), "nf_render_volume_density")
         ctx.model, ctx.n_samples = model, n_samples
@@ -132,16 +157,16 @@ class _TinyRender(torch.autograd.Function):
         d_rgb = _c(d_rgb)
         d_raw = torch.empty_like(raw)
         with torch.cuda.device(dev):
-            ws_n = lib.nf_tiny_bwd_workspace_floats(n * n_samples)
+            ws_n = _fn(model, "bwd_workspace_floats")(n * n_samples)
         ws = torch.empty(ws_n, dtype=torch.float32, device=dev)
-        flat = torch.empty(lib.nf_tiny_grad_floats(), dtype=torch.float32, device=dev)
+        flat = torch.empty(_fn(model, "grad_floats")(), dtype=torch.float32, device=dev)
         with torch.cuda.device(dev):
             H.check(lib.nf_render_volume_density_bwd(H.ptr(raw), H.ptr(depth), H.ptr(d_rgb), n, n_samples, H.ptr(d_raw), H.stream_ptr(dev)),
                     "nf_render_volume_density_bwd")
-            H.check(lib.nf_tiny_mlp_bwd(H.ptr(model.hip_packed_t()), H.ptr(saved), H.ptr(d_raw), n, n_samples, H.ptr(ws), ws_n, H.ptr(flat),
-                                        H.stream_ptr(dev)), "nf_tiny_mlp_bwd")
+            H.check(_fn(model, "mlp_bwd")(H.ptr(_image(model, "pack_bwd")), H.ptr(saved), H.ptr(d_raw), n, n_samples, H.ptr(ws), ws_n,
+                                          H.ptr(flat), H.stream_ptr(dev)), "mlp_bwd")
         grads, off = [], 0
-        for p in (model.layer1.weight, model.layer1.bias, model.layer2.weight, model.layer2.bias, model.layer3.weight, model.layer3.bias):
+        for p in model.hip_param_list():
             grads.append(flat[off:off + p.numel()].view(p.shape))
             off += p.numel()
         return (None, None, None, None, None, *grads)
@@ -154,13 +179,12 @@ def _render_image(height, width, ray_origins, ray_directions, depth, depth_sampl
     depth2 = _c(depth.reshape(-1, depth_samples_per_ray))
     n = ro.shape[0]
     if torch.is_grad_enabled() and any(p.requires_grad for p in model.parameters()):
-        ps = (model.layer1.weight, model.layer1.bias, model.layer2.weight, model.layer2.bias, model.layer3.weight, model.layer3.bias)
-        rgb = _TinyRender.apply(model, _c(ro), _c(rd), depth2, int(depth_samples_per_ray), *ps)
+        rgb = _TinyRender.apply(model, _c(ro), _c(rd), depth2, int(depth_samples_per_ray), *model.hip_param_list())
         return rgb.reshape(height, width, 3)
     raw = torch.empty((n, depth_samples_per_ray, 4), dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
-        H.check(H.lib().nf_tiny_mlp_fwd(H.ptr(model.hip_packed()), H.ptr(_c(ro)), H.ptr(_c(rd)), H.ptr(depth2), 1, n,
-                                        depth_samples_per_ray, H.ptr(raw), H.stream_ptr(dev)), "nf_tiny_mlp_fwd")
+        H.check(_fn(model, "mlp_fwd")(H.ptr(_image(model, "pack")), H.ptr(_c(ro)), H.ptr(_c(rd)), H.ptr(depth2), 1, n,
+                                      depth_samples_per_ray, H.ptr(raw), H.stream_ptr(dev)), "mlp_fwd")
     rgb, _, _ = render_volume_density(raw.reshape(height, width, depth_samples_per_ray, 4), ray_origins, depth)
     return rgb
 
@@ -179,8 +203,7 @@ class GraphedTinyTrainer:
 
     def __init__(self, model, optimizer, height, width, focal_length, near_thresh, far_thresh, depth_samples_per_ray, device,
                  warmup: int = 3):
-        if not isinstance(model, VeryTinyNerfModel) or not model.fused_supported():
-            raise NotImplementedError("the fused tiny kernel is built for VeryTinyNerfModel(128, num_encoding_functions=10)")
+        _api(model)                                                                  # raises for a model without kernels
         self.model, self.optimizer = model, optimizer
         self.h, self.w, self.focal, self.s = int(height), int(width), focal_length, int(depth_samples_per_ray)
         self.near, self.far = float(near_thresh), float(far_thresh)
@@ -244,8 +267,9 @@ def run_one_iter_of_tinynerf(height, width, focal_length, tform_cam2world, near_
                              encoding_function, get_minibatches_function, chunksize, model, encoding_function_args):
     """TN:111-159 (same signature; `encoding_function`, `get_minibatches_function` and `chunksize` are accepted for
     compatibility -- encoding and chunking happen inside the fused kernel).  Returns rgb_predicted (H, W, 3)."""
-    if not isinstance(model, VeryTinyNerfModel) or not model.fused_supported() or int(encoding_function_args) != 10:
-        raise NotImplementedError("the fused tiny kernel is built for VeryTinyNerfModel(128, num_encoding_functions=10)")
+    _api(model)                        # raises for a model without kernels
+    if int(encoding_function_args) != 10:
+        raise NotImplementedError("the fused tiny kernels encode with num_encoding_functions=10 (TN:276)")
     bump_pack_epoch()                  # weight images are rebuilt once per call (fused optimizers do not bump version counters)
     ray_origins, ray_directions = get_ray_bundle(height, width, focal_length, tform_cam2world)
     depth_values = _depths(ray_origins, near_thresh, far_thresh, depth_samples_per_ray, True)       # default randomize=True

@@ -27,7 +27,7 @@ typedef void* nf_stream_t; /* hipStream_t */
 #define NF_EINVAL (-22)
 
 /* ---- library ------------------------------------------------------------------------------------ */
-int         nf_abi_version(void);            /* bumped on any signature / layout change; now 4        */
+int         nf_abi_version(void);            /* bumped on any signature / layout change; now 5        */
 const char* nf_error_string(int code);
 const char* nf_build_info(void);             /* "gfx950 <compiler> <date>"                            */
 
@@ -296,6 +296,29 @@ size_t nf_tiny_bwd_workspace_floats(int64_t n_points);
 int nf_tiny_mlp_bwd(const float* packed_t, const float* saved, const float* d_raw, int64_t n_rays, int n_samples,
                     float* workspace, size_t workspace_floats, float* grads, nf_stream_t stream);
 
+/* ---- BASELINE config 1 read literally ("4-layer MLP"): the tiny path with the reference's FlexibleNeRFModel
+ *      (nerf/models.py:351-422) constructed as FlexibleNeRFModel(num_layers = L, hidden_size = 128, num_encoding_fn_xyz = 10,
+ *      include_input_xyz = True, use_viewdirs = False), L = 2 .. 5 (ABI 5):
+ *        PE(63) -> layer1 (Linear 128, no activation, models.py:402) -> (L - 1) x [layers_xyz.k: Linear 128 + ReLU, models.py:403-410]
+ *        -> fc_out (Linear 4, models.py:422).
+ *      The entry points mirror nf_tiny_* with num_layers in front (other values: NF_EINVAL / size 0).  params: HOST array of
+ *      4 + 2 (L - 1) device pointers in state_dict order (layer1.weight, layer1.bias, layers_xyz.0.weight, layers_xyz.0.bias, ...,
+ *      fc_out.weight, fc_out.bias); nf_flex_mlp_bwd returns the gradients concatenated in the same order
+ *      (nf_flex_grad_floats(L) floats).  Compositing: nf_render_volume_density(_bwd), as for the tiny path.                    */
+size_t nf_flex_packed_floats(int num_layers);
+int nf_flex_pack(int num_layers, const float* const* params, float* packed, nf_stream_t stream);
+int nf_flex_mlp_fwd(int num_layers, const float* packed, const float* ro, const float* rd, const float* depth, int depth_per_ray,
+                    int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
+size_t nf_flex_saved_floats(int num_layers, int64_t n_points);
+int nf_flex_mlp_fwd_train(int num_layers, const float* packed, const float* ro, const float* rd, const float* depth,
+                          int depth_per_ray, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
+size_t nf_flex_packed_bwd_floats(int num_layers);
+int nf_flex_pack_bwd(int num_layers, const float* const* params, float* packed_t, nf_stream_t stream);
+size_t nf_flex_grad_floats(int num_layers);
+size_t nf_flex_bwd_workspace_floats(int num_layers, int64_t n_points);
+int nf_flex_mlp_bwd(int num_layers, const float* packed_t, const float* saved, const float* d_raw, int64_t n_rays, int n_samples,
+                    float* workspace, size_t workspace_floats, float* grads, nf_stream_t stream);
+
 /* ---- eval post-processing on the device -- replaces cast_to_image (eval_transformed_rays.py:184-190) and
  *      torch_normal_map(depthmap, focal, weights, clean=True) (eval_transformed_rays.py:84-119) ------------------------
  * rgb (H,W,3) -> rgb_u8 (H,W,3) = uint8(clamp(x,0,1)*255);  depthmap (H,W) [+ weights (H,W)] -> normals_u8 (H-1,W-1,3).
@@ -381,6 +404,7 @@ int nf_selftest_dw_tables_f32(void);
 int nf_selftest_dw_tables_lcode_f32(void);
 int nf_selftest_dw_tables_bf16(void);
 int nf_selftest_dw_tables_tiny(void);
+int nf_selftest_dw_tables_flex(int num_layers);
 /* gather tables of the four split-bf16 weight streams (host code; out == NULL: number of entries): one code per element of
  * the hi blocks, tensor id << 24 | element offset, 0xFF000000 = zero padding                                            */
 long nf_paper_stream_table_bf16(uint32_t* out, size_t n_entries);

@@ -243,6 +243,44 @@ def make_load_flame():
     np.savez_compressed(os.path.join(OUT, "load_flame.npz"), **blob)
 
 
+def make_flex_tiny(ref):
+    """BASELINE config 1 read literally ("4-layer MLP"): the UNMODIFIED tiny_nerf.run_one_iter_of_tinynerf (TN:111-159) driving the
+    UNMODIFIED nerf.models.FlexibleNeRFModel(num_layers=L, hidden_size=128, num_encoding_fn_xyz=10, use_viewdirs=False) (M:351-422):
+    the rendered 64x64 image for L = 2 .. 5 and, for L = 4, one training step (loss + every parameter gradient)."""
+    TN = RI.import_reference_tiny()
+    pose = O.frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    jit = torch.rand((64, 64, 32), generator=torch.Generator().manual_seed(77))
+    target = O.synthetic_image(64, 64, 13)
+    blob = {}
+    for L in (2, 3, 4, 5):
+        fp = O.flex_init_params(4000 + L, L)
+        fm = ref.models.FlexibleNeRFModel(num_layers=L, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True, use_viewdirs=False)
+        fm.load_state_dict(fp)
+        with RI.injected_random([jit], []):
+            rgb = TN.run_one_iter_of_tinynerf(64, 64, focal, pose, 2.0, 6.0, 32, lambda x, n: ref.positional_encoding(x, n),
+                                              ref.get_minibatches, 16384, fm, 10)
+        rgb2, _, _ = O.tiny_render(fp, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+        print(f"flex tiny L={L}: oracle == reference:", torch.equal(rgb.detach(), rgb2), float((rgb.detach() - rgb2).abs().max()))
+        blob[f"rgb_L{L}"] = rgb.detach().numpy()
+        if L != 4:
+            continue
+        loss = torch.nn.functional.mse_loss(rgb, target)
+        loss.backward()
+        blob["loss_L4"] = loss.detach().numpy()
+        for k, v in fm.named_parameters():
+            blob["grad_L4:" + k] = v.grad.numpy()
+        pp = {k: v.clone().requires_grad_(True) for k, v in fp.items()}
+        rgb3, _, _ = O.tiny_render(pp, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+        torch.nn.functional.mse_loss(rgb3, target).backward()
+        worst = max(float((pp[k].grad - torch.from_numpy(blob["grad_L4:" + k])).norm() / (torch.from_numpy(blob["grad_L4:" + k]).norm() + 1e-30))
+                    for k in fp)
+        print("flex tiny L=4 grad fixture: loss", float(loss), "oracle-vs-reference worst rel L2", worst)
+        assert worst < 1e-5
+    np.savez_compressed(os.path.join(OUT, "flex_tiny_64x64x32.npz"), **blob)
+
+
 def make_tiny_grads(ref):
     """One training step of the UNMODIFIED tiny_nerf.py (TN:282-302): rgb = run_one_iter_of_tinynerf(...), loss = mse(rgb, target),
     loss.backward() -- loss and the six parameter gradients (64x64 image, 32 samples, injected jitter)."""
@@ -332,6 +370,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "tiny_grads":
         make_tiny_grads(ref)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "flex_tiny":
+        make_flex_tiny(ref)
         return
     if len(sys.argv) > 1 and sys.argv[1] == "eval_post":
         make_eval_post()
@@ -437,6 +478,7 @@ def main():
     make_eval_post()
     make_load_flame()
     make_tiny_grads(ref)
+    make_flex_tiny(ref)
 
     # tiny_nerf (BASELINE config 1): 64x64, 32 samples, 3-layer 128-wide MLP, coarse only
     TN = RI.import_reference_tiny()

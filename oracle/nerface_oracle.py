@@ -374,9 +374,36 @@ def tiny_init_params(seed: int, filter_size: int = 128, n_freq: int = 10, dtype=
     return out
 
 
+def flex_init_params(seed: int, num_layers: int = 4, hidden_size: int = 128, n_freq: int = 10, dtype=torch.float32):
+    """state_dict of FlexibleNeRFModel(num_layers, hidden_size, num_encoding_fn_xyz=n_freq, include_input_xyz=True,
+    use_viewdirs=False) (M:351-394): layer1, layers_xyz.0 .. num_layers-2, fc_out; nn.Linear's default range, seeded."""
+    g = torch.Generator().manual_seed(seed)
+    dims = [("layer1", hidden_size, 3 + 3 * 2 * n_freq)]
+    dims += [(f"layers_xyz.{i}", hidden_size, hidden_size) for i in range(num_layers - 1)]
+    dims += [("fc_out", 4, hidden_size)]
+    out = {}
+    for name, o, k in dims:
+        b = 1.0 / math.sqrt(k)
+        out[f"{name}.weight"] = ((torch.rand((o, k), generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+        out[f"{name}.bias"] = ((torch.rand(o, generator=g, dtype=torch.float64) * 2 - 1) * b).to(dtype)
+    return out
+
+
+def flex_mlp(p, x):
+    """FlexibleNeRFModel.forward with use_viewdirs=False and fewer than 6 layers (M:396-422): layer1 WITHOUT activation (M:402),
+    every layers_xyz.i followed by ReLU (M:403-410; the skip of M:404-409 needs i = 4), fc_out (M:422)."""
+    n_hidden = sum(1 for k in p if k.startswith("layers_xyz.") and k.endswith(".weight"))
+    assert n_hidden <= 4, "the skip connection (M:404-409) is not restated"
+    h = _lin(x, p, "layer1")
+    for i in range(n_hidden):
+        h = torch.relu(_lin(h, p, f"layers_xyz.{i}"))
+    return _lin(h, p, "fc_out")
+
+
 def tiny_render(p, height, width, focal, c2w, near, far, n_samples, n_freq=10, jitter: Optional[torch.Tensor] = None):
     """run_one_iter_of_tinynerf (TN:111-159): whole image, coarse only, no background prior,
-    no +1e-6, no |rd| scaling (TN:68-107)."""
+    no +1e-6, no |rd| scaling (TN:68-107).  `p`: VeryTinyNerfModel's state_dict (TN:162-181) or, with a "fc_out.weight" entry,
+    FlexibleNeRFModel's (flex_mlp)."""
     ro, rd = ray_bundle(height, width, np.asarray([float(focal)]), c2w)
     depth = torch.linspace(near, far, n_samples, dtype=ro.dtype)
     if jitter is not None:                                       # TN:46-57
@@ -385,9 +412,12 @@ def tiny_render(p, height, width, focal, c2w, near, far, n_samples, n_freq=10, j
         depth = depth.expand(height, width, n_samples)
     pts = ro[..., None, :] + rd[..., None, :] * depth[..., :, None]
     x = posenc(pts.reshape(-1, 3), n_freq, True)
-    h = torch.relu(_lin(x, p, "layer1"))
-    h = torch.relu(_lin(h, p, "layer2"))
-    raw = _lin(h, p, "layer3").reshape(height, width, n_samples, 4)
+    if "fc_out.weight" in p:
+        raw = flex_mlp(p, x).reshape(height, width, n_samples, 4)
+    else:
+        h = torch.relu(_lin(x, p, "layer1"))
+        h = torch.relu(_lin(h, p, "layer2"))
+        raw = _lin(h, p, "layer3").reshape(height, width, n_samples, 4)
     sigma = torch.relu(raw[..., 3])
     rgb = torch.sigmoid(raw[..., :3])
     big = torch.full_like(depth[..., :1], 1e10)

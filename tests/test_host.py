@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in sorted(declared):
         assert hasattr(hip_lib, name), f"libnerface_hip.so does not export {name}"
     from nerf import _hip
-    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 4          # exact: the ctypes prototypes are written for ONE revision
+    assert hip_lib.nf_abi_version() == _hip.ABI_VERSION == 5          # exact: the ctypes prototypes are written for ONE revision
     assert b"gfx950" in hip_lib.nf_build_info()
     assert hip_lib.nf_error_string(-22).startswith(b"nerface_hip")
 
@@ -271,6 +271,38 @@ def test_tiny_dw_job_table_selftest(hip_lib):
     assert hip_lib.nf_selftest_dw_tables_tiny() == 0
 
 
+def test_flex_tiny_host_side(hip_lib):
+    """The literal "4-layer MLP" of BASELINE config 1 (FlexibleNeRFModel behind the tiny path, nf_flex_*), host side only: the job table
+    of every supported depth writes each slab entry exactly once; sizes follow the layer count; unsupported depths are refused; the
+    product's model class has the reference's parameter names / shapes (M:351-394) and knows which geometries have kernels."""
+    import nerf
+    for L in (2, 3, 4, 5):
+        assert hip_lib.nf_selftest_dw_tables_flex(L) == 0
+        nh = L - 1
+        assert hip_lib.nf_flex_grad_floats(L) == 128 * 63 + 128 + nh * (128 * 128 + 128) + 4 * 128 + 4
+        assert hip_lib.nf_flex_saved_floats(L, 10) == 10 * (64 + 128 * L)
+        assert hip_lib.nf_flex_packed_floats(L) == 8192 + nh * 16384 + 2048 + 128 * L + 16
+        assert hip_lib.nf_flex_packed_bwd_floats(L) == 2048 + nh * 16384
+        assert hip_lib.nf_flex_bwd_workspace_floats(L, 4096 * 32) > 128 * L * 4096 * 32
+        m = nerf.models.FlexibleNeRFModel(num_layers=L, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True, use_viewdirs=False)
+        assert m.fused_supported() and m.num_layers == L
+        assert sum(p.numel() for p in m.hip_param_list()) == hip_lib.nf_flex_grad_floats(L)
+        assert [k for k, _ in m.named_parameters()] == (["layer1.weight", "layer1.bias"] + [f"layers_xyz.{i}.{w}" for i in range(nh) for w in ("weight", "bias")]
+                                                        + ["fc_out.weight", "fc_out.bias"])
+    for L in (0, 1, 6, 8):
+        assert hip_lib.nf_flex_packed_floats(L) == 0 and hip_lib.nf_flex_grad_floats(L) == 0 and hip_lib.nf_selftest_dw_tables_flex(L) == -22
+        assert hip_lib.nf_flex_mlp_fwd(L, None, None, None, None, 1, 4, 4, None, None) == -22
+    assert hip_lib.nf_flex_mlp_fwd(4, None, None, None, None, 1, 0, 4, None, None) == 0                      # no rays: nothing to do
+    assert hip_lib.nf_flex_mlp_fwd(4, None, None, None, None, 1, 4, 4, None, None) == -22
+    # geometries without a kernel construct (state_dict compatibility, M:351-394) and say so
+    full = nerf.models.FlexibleNeRFModel()                                                            # the reference's defaults: view directions
+    assert not full.fused_supported() and set(dict(full.named_parameters())) >= {"layers_dir.0.weight", "fc_alpha.weight", "fc_rgb.weight", "fc_feat.weight"}
+    deep = nerf.models.FlexibleNeRFModel(num_layers=8, hidden_size=128, num_encoding_fn_xyz=10, use_viewdirs=False)
+    assert not deep.fused_supported() and deep.layers_xyz[4].in_features == 63 + 128                   # the skip of M:373
+    with pytest.raises(NotImplementedError):
+        full(torch.zeros(1, 90))
+
+
 def test_cfgnode_roundtrip():
     import yaml
     import nerf
@@ -372,6 +404,7 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device(hip_lib):
     assert lib.nf_weighted_choice_workspace_bytes() >= 4 * (8 + 4096)
     assert lib.nf_paper_bwd_workspace_floats(2048 * 128) > 2176 * 2048 * 128
     assert lib.nf_tiny_bwd_workspace_floats(4096 * 32) > 0
+    assert lib.nf_flex_mlp_bwd(4, None, None, None, 4, 4, None, 0, None, None) == EINVAL
 
 
 def test_launcher_host_helpers():

@@ -225,6 +225,46 @@ def test_tiny_gradient_fixture():
         assert float((v.grad - want).norm() / (want.norm() + 1e-30)) < 1e-5, k
 
 
+def test_flex_tiny_golden_and_gradient_fixture():
+    """BASELINE config 1 read literally ("4-layer MLP"): the oracle's restatement of FlexibleNeRFModel.forward (M:396-422,
+    use_viewdirs=False) behind the tiny path against the unmodified reference's own output for 2 .. 5 layers, and the oracle's
+    autograd of the 4-layer training step against the reference's autograd (tests/golden/flex_tiny_64x64x32.npz)."""
+    g = np.load(os.path.join(GOLD, "flex_tiny_64x64x32.npz"))
+    pose = O.frame_pose(7)
+    pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
+    jit = torch.rand((64, 64, 32), generator=torch.Generator().manual_seed(77))
+    focal = torch.tensor(138.88 * 64 / 100.0)
+    for L in (2, 3, 4, 5):
+        p = O.flex_init_params(4000 + L, L)
+        assert len(p) == 2 * (L + 1) and p["layer1.weight"].shape == (128, 63) and p["fc_out.weight"].shape == (4, 128)
+        rgb, _, _ = O.tiny_render(p, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+        d = np.abs(rgb.numpy() - g[f"rgb_L{L}"]).max()
+        assert np.array_equal(rgb.numpy(), g[f"rgb_L{L}"]) or d < 1e-5, (L, d)
+    pp = {k: v.clone().requires_grad_(True) for k, v in O.flex_init_params(4004, 4).items()}
+    rgb, _, _ = O.tiny_render(pp, 64, 64, focal, pose, 2.0, 6.0, 32, 10, jitter=jit)
+    loss = torch.nn.functional.mse_loss(rgb, O.synthetic_image(64, 64, 13))
+    loss.backward()
+    assert abs(float(loss) - float(g["loss_L4"])) < 1e-6
+    for k, v in pp.items():
+        want = torch.from_numpy(g["grad_L4:" + k])
+        assert float((v.grad - want).norm() / (want.norm() + 1e-30)) < 1e-5, k
+
+
+def test_flex_restatement_equals_live_reference_model():
+    """When the unmodified reference can be imported here: flex_mlp == FlexibleNeRFModel.forward on random encoded points, bit for bit."""
+    from oracle import ref_import as RI
+    if not RI.reference_importable():
+        pytest.skip("reference not importable here")
+    ref = RI.import_reference()
+    x = torch.randn((257, 63), generator=torch.Generator().manual_seed(5))
+    for L in (2, 4, 5):
+        p = O.flex_init_params(17 + L, L)
+        m = ref.models.FlexibleNeRFModel(num_layers=L, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True, use_viewdirs=False)
+        m.load_state_dict(p)
+        with torch.no_grad():
+            assert torch.equal(m(x), O.flex_mlp(p, x)), L
+
+
 def test_split_emulation_model_is_sane():
     """oracle/split_emulation.py (the numerical model behind profiles/r05_split_products.md): the operand columns that go through the
     MFMAs are the ones the kernels stream (the expression / latent / near / far columns are folded into biases in f32), and on a few
