@@ -278,13 +278,22 @@ def bench_train(args, nerf, model_c, model_f, dev, rank, world, dist, emit=True)
     return result
 
 
-def bench_tiny(dev, steps=20):
+def bench_tiny(dev, steps=20, flex_layers=0):
     """configs[0]: tiny_nerf 64x64 image, 32 samples (TN:111-159) -- the fused tiny kernels on the device.  Returns the result
-    and the inputs (weights, pose, focal) so that cpu_baseline_tiny can time the CPU oracle on the same image."""
+    and the inputs (weights, pose, focal) so that cpu_baseline_tiny can time the CPU oracle on the same image.
+    flex_layers = L > 0: BASELINE's "4-layer MLP" read literally -- the reference's FlexibleNeRFModel(num_layers=L, 128, use_viewdirs=False)
+    (M:351-422) in place of the script's own 3-Linear VeryTinyNerfModel (nf_flex_* kernels)."""
     import tiny_nerf as TN
+    import nerf
     torch.cuda.empty_cache()                                            # the eval / training legs leave GBs of cached blocks behind
     torch.manual_seed(9458)                                             # TN:264
-    model = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
+
+    def new_model():
+        if flex_layers:
+            return nerf.models.FlexibleNeRFModel(num_layers=flex_layers, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True,
+                                                 use_viewdirs=False).to(dev)
+        return TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
+    model = new_model()
     pose = frame_pose(7)
     pose[:3, 3] = torch.tensor([0.3, -0.2, 4.0])
     focal = torch.tensor(138.88 * 64 / 100.0)
@@ -325,7 +334,7 @@ def bench_tiny(dev, steps=20):
         ms_train = min(ms_train, 1e3 * (time.perf_counter() - t0) / steps)
     assert bool(torch.isfinite(loss))
     # the same loop body captured once in a HIP graph and replayed (tiny_nerf.GraphedTinyTrainer; jitter drawn on the device)
-    model_g = TN.VeryTinyNerfModel(num_encoding_functions=10).to(dev)
+    model_g = new_model()
     model_g.load_state_dict(model.state_dict())
     trainer = TN.GraphedTinyTrainer(model_g, torch.optim.Adam(model_g.parameters(), lr=5e-3, capturable=True), 64, 64, focal, 2.0, 6.0, 32, dev)
     for _ in range(3):
@@ -337,7 +346,9 @@ def bench_tiny(dev, steps=20):
     torch.cuda.synchronize()
     ms_graph = 1e3 * (time.perf_counter() - t0) / (5 * steps)
     assert bool(torch.isfinite(loss_g))
-    res = {"workload": "configs[0]: tiny_nerf 64x64 image, 32 samples per ray, VeryTinyNerfModel (63-128-128-4), forward",
+    arch = (f"FlexibleNeRFModel(num_layers={flex_layers}) (63-128" + "-128" * (flex_layers - 1) + "-4, first layer linear)") if flex_layers \
+        else "VeryTinyNerfModel (63-128-128-4)"
+    res = {"workload": f"configs[0]: tiny_nerf 64x64 image, 32 samples per ray, {arch}, forward",
            "value": 4096 / (ms * 1e-3), "unit": "rays/s", "ms_per_image": ms, "images": steps,
            "train": {"ms_per_iter": ms_train, "value": 4096 / (ms_train * 1e-3), "unit": "rays/s",
                      "what": "forward + mse + backward (HIP kernels) + Adam per 64x64 image (TN:282-302)",
@@ -659,6 +670,12 @@ def main():
                     line["tiny"]["cpu_baseline"] = cpu_baseline_tiny(*tiny_inputs)
             except Exception as e:                                # an extra must never cost the headline
                 line["tiny"] = {"error": repr(e)}
+            try:                                                  # configs[0] read literally: "4-layer MLP" (FlexibleNeRFModel, M:351-422)
+                line["tiny4"], tiny_inputs = bench_tiny(dev, flex_layers=4)
+                if not args.no_cpu_baseline:
+                    line["tiny4"]["cpu_baseline"] = cpu_baseline_tiny(*tiny_inputs, flex_layers=4)
+            except Exception as e:
+                line["tiny4"] = {"error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 torch.cuda.empty_cache()
@@ -819,6 +836,7 @@ def summary_of(line):
               "cpu_threads": g("cpu_baseline", "cores"),
               "tiny_rays_s": g("tiny", "value"), "tiny_cpu_rays_s": g("tiny", "cpu_baseline", "value"),
               "tiny_cpu_kind": g("tiny", "cpu_baseline", "kind"),
+              "tiny4_rays_s": g("tiny4", "value"), "tiny4_cpu_rays_s": g("tiny4", "cpu_baseline", "value"),
               "launcher_eval_frames_s": g("launcher", "launcher_eval_frames_s"),
               "launcher_wall_over_gpu": g("launcher", "launcher_wall_over_gpu")})
     # north_star's ratio "x the reference on the same GPU at matched PSNR": quoted on f16x3, the fastest arithmetic that keeps the gate at

@@ -162,10 +162,11 @@ def cpu_baseline(n_rays=12288):
             "parity_on_sample": parity}
 
 
-def cpu_baseline_tiny(params, pose, focal, reps=3):
+def cpu_baseline_tiny(params, pose, focal, reps=3, flex_layers=0):
     """configs[0] on the host, kind "reference": the UNMODIFIED tiny_nerf.py's own `run_one_iter_of_tinynerf` (TN:111-159) with its
     own VeryTinyNerfModel on the same weights / pose (imported through oracle/ref_import.import_reference_tiny: live tree or the
-    travelling archive); the oracle port of the same image beside it.  kind "port" only where the reference is absent."""
+    travelling archive); the oracle port of the same image beside it.  kind "port" only where the reference is absent.
+    flex_layers = L > 0: the same script driving the reference's own nerf.models.FlexibleNeRFModel(num_layers=L, 128, use_viewdirs=False)."""
     from oracle import nerface_oracle as O
     from oracle import ref_import as RI
     torch.set_num_threads(min(os.cpu_count() or 1, 16))                 # 131k points x 128 features: more threads only add overhead
@@ -180,7 +181,8 @@ def cpu_baseline_tiny(params, pose, focal, reps=3):
         try:
             ref = RI.import_reference()
             TN = RI.import_reference_tiny()
-            tm = TN.VeryTinyNerfModel(num_encoding_functions=10)
+            tm = (ref.models.FlexibleNeRFModel(num_layers=flex_layers, hidden_size=128, num_encoding_fn_xyz=10, include_input_xyz=True,
+                                               use_viewdirs=False) if flex_layers else TN.VeryTinyNerfModel(num_encoding_functions=10))
             tm.load_state_dict(params)
             enc = ref.positional_encoding                                  # what the script passes (TN:230, 288)
             with torch.no_grad():

@@ -218,6 +218,7 @@ def test_bench_compact_line_fits_the_driver_record():
             k["frac_executed_mfma"] = 0.31234567890123456
     line["cpu_baseline"]["parity_on_sample"]["f16x2"] = dict(line["cpu_baseline"]["parity_on_sample"]["f16x3"])
     line["tiny"]["cpu_baseline"].update(kind="reference")
+    line["tiny4"] = copy.deepcopy(line["tiny"])                            # round 6: configs[0] read literally (4-layer FlexibleNeRFModel)
     line["summary"] = B.summary_of(line)
     assert all(v is not None for k, v in line["summary"].items() if k != "train_allreduce_us"), [k for k, v in line["summary"].items() if v is None]
     c = B.compact_line(line)
@@ -235,7 +236,7 @@ def test_bench_compact_line_fits_the_driver_record():
     assert all(not isinstance(v, (dict, list)) for k, v in c["roofline"].items())
     assert abs(c["value"] - line["value"]) <= 1e-5 * line["value"] and c["roofline"]["frac"] == round(line["roofline"]["frac"], 6)
     for k in ("train_ms_bf", "tr_bf_fwd_ms_2400_est", "tr_bf_fwd_frac_mfma", "tr_f16_chain_frac_mfma", "f16_rays_s", "pattern_store_gbs", "product_over_eager",
-              "launcher_eval_frames_s", "eager_rocm_kind", "eager_rocm_min_rays_s", "tiny_cpu_kind", "power_cap_w", "w_f16", "mhz_f16", "x2_rays_s",
+              "launcher_eval_frames_s", "eager_rocm_kind", "eager_rocm_min_rays_s", "tiny_cpu_kind", "tiny4_rays_s", "tiny4_cpu_rays_s", "power_cap_w", "w_f16", "mhz_f16", "x2_rays_s",
               "matched_psnr_over_eager_f16x3", "speed_only_over_eager_f16x2", "f16_gate_30db_worst_db", "x2_gate_30db_worst_db", "bf_gate_30db_worst_db",
               "f16_gate_30db_1024rays_db", "x2_gate_random_db", "f16_self_psnr_min_db", "rank_ms_max", "cpu_threads"):
         assert k in c["summary"], k
