@@ -310,10 +310,11 @@ def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, n_samples: int, u: Opt
 
 def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: float, n_coarse: int, n_fine: int,
                 t_rand=None, noise_c=None, u=None, noise_f=None, stages: Optional[dict] = None, rd_view=None, mlp=None,
-                point_chunk: int = 65536, lindisp: bool = False):
+                point_chunk: int = 65536, lindisp: bool = False, white_background: bool = False):
     """Coarse pass -> hierarchical resample -> fine pass.  Returns the 7-tuple of T:162
     (rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, weights_f[:, -1]).  Random tensors are injected
-    (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates."""
+    (None = deterministic: perturb off / no noise / det sampling).  ``stages`` collects intermediates.
+    white_background: the switch both integrator calls receive (T:104, T:150 -> V:71-72)."""
     R = ro.shape[0]
     st = stages if stages is not None else {}
     mlp_fn = mlp if mlp is not None else globals()["paper_mlp"]             # model family (default: the paper model)
@@ -329,7 +330,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
     st["raw_c_mlp"] = raw.clone()
     if bg is not None:
         raw[:, -1, :3] = bg.to(raw.dtype)
-    rgb_c, disp_c, acc_c, w_c = volume_render(raw, z, rd, noise_c, has_background=bg is not None)
+    rgb_c, disp_c, acc_c, w_c = volume_render(raw, z, rd, noise_c, has_background=bg is not None, white_background=white_background)
     st.update(z_c=z, w_c=w_c)
     if n_fine <= 0:
         return rgb_c, disp_c, acc_c, None, None, None, w_c[:, -1]
@@ -340,7 +341,7 @@ def render_rays(p_coarse, p_fine, ro, rd, expr, latent, bg, near: float, far: fl
     st["raw_f_mlp"] = raw_f.clone()
     if bg is not None:
         raw_f[:, -1, :3] = bg.to(raw_f.dtype)
-    rgb_f, disp_f, acc_f, w_f = volume_render(raw_f, z_f, rd, noise_f, has_background=bg is not None)
+    rgb_f, disp_f, acc_f, w_f = volume_render(raw_f, z_f, rd, noise_f, has_background=bg is not None, white_background=white_background)
     st.update(z_samples=z_s, z_f=z_f, w_f=w_f)
     return rgb_c, disp_c, acc_c, rgb_f, disp_f, acc_f, w_f[:, -1]
 

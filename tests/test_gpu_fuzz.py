@@ -1,0 +1,76 @@
+"""Seeded fuzz of nerf.run_one_iter_of_nerf (HIP path) against the CPU oracle over the sizes and switches the fixed cases do not reach:
+odd / tiny / large sample counts on both passes (the general-size resample + merge kernel as well as the <= 128 fast path), ray counts
+that leave partial wave tiles and partial workgroups, ragged ray chunks, every sampler / integrator switch (perturb, lindisp, density noise,
+white background, no background prior, coarse only).  SURVEY 8(d)'s density head and SURVEY 8(d)(i)'s gates.  GPU only."""
+import random
+
+import pytest
+import torch
+
+from oracle import cases as C
+from oracle import nerface_oracle as O
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+NAMES7 = ["rgb_c", "disp_c", "acc_c", "rgb_f", "disp_f", "acc_f", "w_last"]
+# colours 2e-5, weights 1e-5; disparities are 1.25 .. 5 (near 0.2, far 0.8): 2e-5 absolute is <= 1.6e-5 relative
+GATE = dict(rgb_c=2e-5, rgb_f=2e-5, acc_c=1e-5, acc_f=1e-5, w_last=1e-5, disp_c=2e-5, disp_f=2e-5)
+
+
+def _configs():
+    rnd = random.Random(20260930)
+    out = []
+    for k in range(18):
+        nc = rnd.choice([4, 5, 7, 16, 33, 64, 64, 65, 100, 128, 129, 150])
+        nf = rnd.choice([0, 1, 2, 3, 31, 64, 64, 65, 127, 128, 128, 129, 160])
+        stochastic = rnd.random() < 0.6
+        out.append(dict(frame=rnd.randrange(0, 400), n_rays=rnd.choice([1, 2, 31, 33, 63, 64, 65, 127, 129, 200, 257]), n_coarse=nc, n_fine=nf,
+                        stochastic=stochastic, noise_std=rnd.choice([0.0, 0.1, 1.0]) if stochastic else 0.0, boost="survey",
+                        lindisp=rnd.random() < 0.3, white=rnd.random() < 0.25, no_bg=rnd.random() < 0.2,
+                        # ragged ray chunks only where no random tensors are drawn (they are drawn per chunk, in the chunk's shape)
+                        chunk=None if stochastic else rnd.choice([None, 7, 32, 50])))
+    return out
+
+
+CONFIGS = _configs()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])                   # f16x3 (split-fp16, fp32-class) is held to the f32 gates
+@pytest.mark.parametrize("k", range(len(CONFIGS)))
+def test_fuzz_against_oracle(hip_lib, gpu, k, precision):
+    import nerf
+    nerf.set_mlp_precision(precision)
+    cfg = dict(CONFIGS[k])
+    white, no_bg, chunk = cfg.pop("white"), cfg.pop("no_bg"), cfg.pop("chunk")
+    name = f"fuzz_{k}"
+    C.CASES[name] = cfg
+    try:
+        c = C.build_case(name)
+    finally:
+        del C.CASES[name]
+    bg = None if no_bg else c["bg"]
+    ref = O.render_rays(c["p_coarse"], c["p_fine"], c["ro"], c["rd"], c["expr"], c["latent"], bg, O.NEAR, O.FAR, c["n_coarse"], c["n_fine"],
+                        t_rand=c["t_rand"], noise_c=c["noise_c"], u=c["u"], noise_f=c["noise_f"], lindisp=bool(c.get("lindisp", False)),
+                        white_background=white)
+    mc = U.make_model(nerf, c["p_coarse"], gpu)
+    mf = U.make_model(nerf, c["p_fine"], gpu) if c["n_fine"] > 0 else None
+    opt = U.make_options(nerf, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"], chunk or 65536, white=white,
+                         lindisp=bool(c.get("lindisp", False)))
+    ex, ed = U.encoders(nerf)
+    rands, randns = U.case_random_lists(c)
+    with torch.no_grad(), U.injected_random(rands, randns):
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train", encode_position_fn=ex,
+                                        encode_direction_fn=ed, expressions=c["expr"].to(gpu),
+                                        background_prior=None if bg is None else bg.to(gpu), latent_code=c["latent"].to(gpu))
+    desc = {kk: v for kk, v in CONFIGS[k].items() if kk != "boost"}
+    worst = {}
+    for n, got, want in zip(NAMES7, out, ref):
+        if want is None:
+            assert got is None, (n, desc)
+            continue
+        assert got is not None and tuple(got.shape) == tuple(want.shape), (n, desc)
+        assert bool(torch.isfinite(got).all()), (n, desc)
+        worst[n] = float((got.cpu() - want).abs().max())
+    print(f"[fuzz {k} {precision}] {desc}: " + " ".join(f"{n}={v:.1e}" for n, v in worst.items()))
+    for n, v in worst.items():
+        assert v <= GATE[n], (n, v, desc)
