@@ -253,15 +253,15 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 2 * 16 * 64, lane);
         NF_PE_B(2); nf_chunk<NT, 16, false>(acc, w, bj, st.bias);
         nf_load_w16<16>(w, Wi, OFF_L0 / 4 + 3 * 16 * 64, lane);
-        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1>(acc, w, bj, st, Wi, OFF_L1 / 4, Ci, B_L1, act4, lane);
+        NF_PE_B(3); nf_tail<NT, 16, 16, 16, 1, NF_ONEWAIT>(acc, w, bj, st, Wi, OFF_L1 / 4, Ci, B_L1, act4, lane);
     }
     // ---- layers_xyz.1, .2 (ReLU of the previous layer on read) ------------------------------------------
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L1 / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L2 / 4, Ci, B_L2, act4, lane);
+    nf_tail<NT, 16, 16, 16, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_L2 / 4, Ci, B_L2, act4, lane);
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L2 / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 16, 0>(acc, st.wb, bj, st, Wi, OFF_L3 / 4, Ci, B_L3, act4, lane);
+    nf_tail<NT, 16, 16, 16, 0, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_L3 / 4, Ci, B_L3, act4, lane);
     // ---- layers_xyz.3 : [PE | h] -> 256 (skip connection, M:246) ----------------------------------------
     NF_PE_B(0); nf_chunk<NT, 16, true>(acc, st.wa, bj, st.bias);
     nf_load_w16<16>(st.wa, Wi, OFF_L3 / 4 + 4 * 16 * 64, lane);            // the first slab chunk, three chunks ahead
@@ -277,18 +277,18 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
     }
     nf_seg_lds<NT, 16, false, true>(acc, st, Wi, OFF_L3 / 4 + 4 * 16 * 64, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L4 / 4, Ci, B_L4, act4, lane);
+    nf_tail<NT, 16, 16, 16, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_L4 / 4, Ci, B_L4, act4, lane);
     // ---- layers_xyz.4, .5 --------------------------------------------------------------------------------
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L4 / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_L5 / 4, Ci, B_L5, act4, lane);
+    nf_tail<NT, 16, 16, 16, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_L5 / 4, Ci, B_L5, act4, lane);
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_L5 / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 16, 1>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
+    nf_tail<NT, 16, 16, 16, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_FEAT / 4, Ci, B_FEAT, act4, lane);
     // ---- fc_feat (no activation, M:250: layers_dir.0 reads it as stored) -----------------------------------
     nf_seg_lds<NT, 16, true, true>(acc, st, Wi, OFF_FEAT / 4, 16, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 16, 16, 9, 1>(acc, st.wb, bj, st, Wi, OFF_D0 / 4, Ci, B_D0, act4, lane);
+    nf_tail<NT, 16, 16, 9, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_D0 / 4, Ci, B_D0, act4, lane);
     // ---- layers_dir.0 : [feat | dir slots] -> 128; tile 8 row 0 = fc_alpha(feat) (Q2) -----------------------
     float sigma_raw[NT];
     {
@@ -299,17 +299,17 @@ k_paper_mlp_fwd(const float* __restrict__ packed, const float* __restrict__ cond
         nf_chunk<NT, 9, false>(acc, st.wb, bj, st.bias);
 #pragma unroll
         for (int t = 0; t < NT; ++t) bj[t] = dirf[t][0];
-        nf_tail<NT, 9, 8, 8, 1>(acc, wd, bj, st, Wi, OFF_D1 / 4, Ci, B_D1, act4, lane);
+        nf_tail<NT, 9, 8, 8, 1, NF_ONEWAIT>(acc, wd, bj, st, Wi, OFF_D1 / 4, Ci, B_D1, act4, lane);
 #pragma unroll
         for (int t = 0; t < NT; ++t) sigma_raw[t] = acc[t][8].x;
     }
     // ---- layers_dir.1, .2 -----------------------------------------------------------------------------------
     nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D1 / 4, 8, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 8, 8, 8, 1>(acc, st.wb, bj, st, Wi, OFF_D2 / 4, Ci, B_D2, act4, lane);
+    nf_tail<NT, 8, 8, 8, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_D2 / 4, Ci, B_D2, act4, lane);
     nf_seg_lds<NT, 8, true, true>(acc, st, Wi, OFF_D2 / 4, 8, act4, lane);
     nf_pending_b<NT, true>(bj, st);
-    nf_tail<NT, 8, 8, 1, 1>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
+    nf_tail<NT, 8, 8, 1, 1, NF_ONEWAIT>(acc, st.wb, bj, st, Wi, OFF_RGB / 4, Ci, B_RGB, act4, lane);
 #undef NF_PE_B
     // ---- fc_rgb -------------------------------------------------------------------------------------------
     nf_seg_lds<NT, 1, true, true>(acc, st, Wi, OFF_RGB / 4, 8, act4, lane);
@@ -505,6 +505,13 @@ k_paper_mlp_fwd_save(const float* __restrict__ packed, const float* __restrict__
     }
 }
 
+#ifndef NF_F32_RR
+#define NF_F32_RR 0
+#endif
+#if NF_F32_RR
+#include "nf_mlp_rr.h"
+#endif
+
 static int nf_launch_fwd(const float* packed, const float* cond, const float* ro, const float* rd, const float* rd_view,
                          const float* z, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream) {
     if (n_rays == 0 && n_samples > 0) return 0;            // nothing to do (empty tensors have NULL data pointers)
@@ -520,8 +527,13 @@ static int nf_launch_fwd(const float* packed, const float* cond, const float* ro
         hipLaunchKernelGGL((k_paper_mlp_fwd_save<NT>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw, saved);
     else
+#if NF_F32_RR
+        hipLaunchKernelGGL((k_paper_mlp_fwd_rr<NT>), dim3((unsigned)(grid < nf_cu_count() ? grid : nf_cu_count())), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
+                           cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+#else
         hipLaunchKernelGGL((k_paper_mlp_fwd<NT>), dim3((unsigned)(grid < nf_cu_count() ? grid : nf_cu_count())), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed,
                            cond, ro, rd, rd_view ? rd_view : rd, z, n_points, n_samples, raw);
+#endif
     NF_RETURN_LAUNCH();
 }
 

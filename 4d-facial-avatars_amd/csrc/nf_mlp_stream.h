@@ -21,6 +21,15 @@
 #ifndef NF_TAIL_LAG
 #define NF_TAIL_LAG 2
 #endif
+// NF_ONEWAIT (inference kernel only; experiment): one `s_waitcnt vmcnt(0)` at the top of a K chunk instead of one counted wait per output
+// tile.  With the next chunk's 16 weight loads spread one per tile over the whole chunk, every tile's first MFMA needs its own
+// `s_waitcnt vmcnt(15)` -- 16 extra issue slots per 128 MFMAs in a one-wave-per-SIMD stream where a non-MFMA instruction costs ~5 cycles
+// (profiles/r06_f32_rr.md).  Here the loads go out two per tile behind the FIRST half of the chunk's tiles, so that they are at least half
+// a chunk (2048 cycles) old at the next chunk's top, where a single wait covers them all.
+#ifndef NF_ONEWAIT
+#define NF_ONEWAIT 0
+#endif
+#define NF_WAIT_VM0() __builtin_amdgcn_s_waitcnt(0x0F70)          // vmcnt(0), expcnt / lgkmcnt unconstrained (gfx9 encoding)
 
 template <int NT>
 struct NfStream {
@@ -158,6 +167,8 @@ __device__ __forceinline__ void nf_half(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
                                         const f32x4 (&bias)[16], const NfW& W, unsigned wsrc, const f32x4* act4, int lane, int ni_next, Side& side,
                                         int step, uint64_t (&m64)[NT], f32x4 (&bp)[NT]) {
     constexpr int NS = ST ? Side::N : 0, NR = RD ? Side::N : 0;
+    constexpr bool onewait = NF_ONEWAIT != 0 && Side::N == 0 && !MASK && NO >= 2;
+    if (onewait) NF_WAIT_VM0();                   // this chunk's weights (and, FIRST, the bias): requested at least half a chunk ago
     f32x4 b[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) b[t] = RELU_IN ? nf_relu_i(raw[t]) : raw[t];
@@ -183,7 +194,12 @@ __device__ __forceinline__ void nf_half(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        if (onewait) {
+            constexpr int H = (NO + 1) / 2;       // loads behind the first H tiles
+            if (no < H) NF_SGB_N(0x020, (no + 1) * NO / H - no * NO / H);
+        } else {
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
         NF_SGB_N(0x040, (no + 1) * NS / NO - no * NS / NO);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -229,13 +245,14 @@ __device__ __forceinline__ void nf_pending_b(f32x4 (&b)[NT], const NfStream<NT>&
 // the slab, 0 = from register chunks.  Leaves the next layer's first weight chunk in st.wa, its bias in st.bias and (NEXT_B) its
 // first B fragment, as stored, in st.b0.
 // The accumulators go to the slab as they are, straight from the accumulator registers: whoever reads the slab applies the ReLU.
-template <int NT, int NO, int NO_ST, int NO_NEXT, int NEXT_B>
+template <int NT, int NO, int NO_ST, int NO_NEXT, int NEXT_B, int ONEWAIT = 0>
 __device__ __forceinline__ void nf_tail(f32x4 (&acc)[NT][16], const f32x4 (&w)[16], const f32x4 (&b)[NT], NfStream<NT>& st,
                                         const NfW& W, unsigned wnext, const NfW& C, unsigned bias_next, f32x4* act4, int lane) {
     constexpr int LAG = NF_TAIL_LAG;
     constexpr int NL = 2 * NO_NEXT;                                    // prefetch loads, spread over the NO tile steps
     const int g = lane >> 4, c = lane & 15;
     __builtin_amdgcn_sched_barrier(0);
+    if (ONEWAIT) NF_WAIT_VM0();
     nf_load_bias<NO_NEXT>(st.bias, C, bias_next, lane);
     nf_load_w16<NO_NEXT>(st.wa, W, wnext, lane);
     f32x4 braw[NT];
@@ -260,7 +277,12 @@ __device__ __forceinline__ void nf_tail(f32x4 (&acc)[NT][16], const f32x4 (&w)[1
     for (int no = 0; no < NO + LAG; ++no) {
         if (no < NO) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
-            NF_SGB_N(0x020, (no + 1) * NL / NO - no * NL / NO);
+            if (ONEWAIT) {                            // all prefetch loads behind the first half of the tiles (see NF_ONEWAIT)
+                constexpr int H = (NO + 1) / 2;
+                if (no < H) NF_SGB_N(0x020, (no + 1) * NL / H - no * NL / H);
+            } else {
+                NF_SGB_N(0x020, (no + 1) * NL / NO - no * NL / NO);
+            }
         }
         if (no >= LAG && no - LAG < NO_ST) __builtin_amdgcn_sched_group_barrier(0x200, NT, 0);
         if (no == LAG && NEXT_B != 0) __builtin_amdgcn_sched_group_barrier(0x100, NT, 0);

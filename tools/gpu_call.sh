@@ -9,6 +9,7 @@
 #   sweep [frames]             tools/frame_gate_sweep.py                               -> gate_sweep.txt / .json
 #   ab <variant> [notime]      tools/split_fwd_ab.py on the default library and on lib/libnerface_hip_<variant>.so, hashes diffed -> ab_<variant>.txt
 #   pmcmix <prec> [variant]    instruction-mix PMC passes (3 passes, 8 SQ counters each) over tools/pmc_one_launch.py <prec> -> pmc_<prec>[_variant].md
+#   pmcset <prec> <variant|-> <counters...>  one PMC pass with the named counters over tools/pmc_one_launch.py -> pmcset_<prec>[_variant].md
 #   pmctrain <prec> [variant]  the same passes over tools/pmc_train_launch.py <prec>   -> pmc_train_<prec>[_variant].md
 #   bench [bench.py args]      python bench.py ...                                     -> bench_line.json (last line), bench.log
 #   stats [bench.py args]      rocprofv3 --kernel-trace --stats of bench.py --no-extras --no-cpu-baseline ... -> kernel_stats.md
@@ -52,6 +53,13 @@ run_recipe() {
            echo "== hashes that differ between default and $v:"; diff <(grep ^hash $O/ab_default.txt) <(grep ^hash $O/ab_$v.txt) | head -40
            echo "== times (default | $v):"; paste -d'|' <(grep ^time $O/ab_default.txt) <(grep ^time $O/ab_$v.txt | sed 's/^time [a-z0-9 ]*: //') ;;
     pmcmix)   pmc_passes "pmc_$1${2:+_$2}" pmc_one_launch.py "$1" "$2" ;;
+    pmcset)   # pmcset <prec> <variant or -> <counter> [counter ...]: one extra PMC pass with the given counters -> pmcset_<prec>[_variant].md
+              local prec=$1 var=$2; shift 2; [ "$var" = "-" ] && var=""
+              local lib=""; [ -n "$var" ] && lib=$L/libnerface_hip_$var.so
+              rm -rf /tmp/pmc_x
+              ( cd /tmp && NERFACE_HIP_LIB=$lib timeout 300 rocprofv3 --kernel-trace --pmc "$@" -d /tmp/pmc_x -o p -- python $ROOT/tools/pmc_one_launch.py $prec > $O/pmcset_$prec${var:+_$var}.log 2>&1 ); echo "pmcset rc=$?"
+              python tools/rocpd_summary.py pmc $(find /tmp/pmc_x -name '*.db') > $O/pmcset_$prec${var:+_$var}.md 2>&1
+              grep -E "mlp_fwd|counter|^\|" $O/pmcset_$prec${var:+_$var}.md | cut -c1-200 | head -20; tail -3 $O/pmcset_$prec${var:+_$var}.log ;;
     pmctrain) pmc_passes "pmc_train_$1${2:+_$2}" pmc_train_launch.py "$1" "$2" ;;
     bench) timeout 1500 python bench.py "$@" > $O/bench.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench.log > $O/bench_line.json; cp gpurun_out/bench_detail.json $O/ 2>/dev/null; tail -c 2500 $O/bench_line.json ;;
     stats) rm -rf /tmp/stats; ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/stats -o s -- python $ROOT/bench.py --no-extras --no-cpu-baseline "$@" > $O/stats.log 2>&1 ); echo "stats rc=$?"
