@@ -17,6 +17,9 @@
 #ifndef NF_RR_VALU_MODE
 #define NF_RR_VALU_MODE 0            // where the next fragment's ReLU sits in a chunk: 0 = behind the first tile, 1 / 2 = halves / quarters behind the first tiles, 4 = free
 #endif
+#ifndef NF_RR_PAIR
+#define NF_RR_PAIR 0                 // 1: MFMAs of two output tiles interleaved (four independent accumulators in flight)
+#endif
 #ifndef NF_RR_NOLOAD
 #define NF_RR_NOLOAD 0
 #endif
@@ -73,6 +76,25 @@ __device__ __forceinline__ void nf_rr_step(f32x4 (&out)[NT][16], NfRrRing& R, co
                                            f32x4 (&dead)[NT][16], int nb0, const NfW& C, unsigned bias_off, const NfRrLane& L) {
     static_assert(NO_N <= NO, "the next chunk's tiles ride behind this chunk's");
     constexpr int PN = nf_rr_next_pos<POS, NO>();
+#if NF_RR_PAIR
+    // tiles in pairs: four independent accumulators between two MFMAs on the same one (distance 4 instead of 2)
+#pragma unroll
+    for (int no = 0; no < NO; no += 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+                    if (no + q < NO)
+                        out[t][no + q] = __builtin_amdgcn_mfma_f32_16x16x4f32(R.g[(POS + (no + q) / 8) % 3][(no + q) % 8][r], b[t][r], out[t][no + q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            if (!NF_RR_NOLOAD && no + q < NO_N) nf_rr_w1<PN>(R, no + q, W, wn4, L);
+            if (!NF_RR_NOLOAD && no + q < NB) nf_rr_bias<NT>(dead, nb0 + no + q, C, bias_off, L);
+        }
+    }
+#else
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
 #pragma unroll
@@ -83,6 +105,7 @@ __device__ __forceinline__ void nf_rr_step(f32x4 (&out)[NT][16], NfRrRing& R, co
         if (!NF_RR_NOLOAD && no < NO_N) nf_rr_w1<PN>(R, no, W, wn4, L);
         if (!NF_RR_NOLOAD && no < NB) nf_rr_bias<NT>(dead, nb0 + no, C, bias_off, L);
     }
+#endif
 #pragma unroll
     for (int no = 0; no < NO; ++no) {
         __builtin_amdgcn_sched_group_barrier(0x008, 4 * NT, 0);
