@@ -215,6 +215,7 @@ static int nf_flex_fwd_impl(const float* packed, const float* ro, const float* r
     const int64_t per_block = (int64_t)NF_MLP_WAVES * 16 * NT;
     const int64_t grid = (n_points + per_block - 1) / per_block;
     if (grid > 0x7fffffff) return NF_EINVAL;
+    if (saved && n_points >= ((int64_t)1 << 22)) return NF_EINVAL;       // the save path addresses a 128-wide section with 32-bit byte offsets (512 B per point)
     if (saved)
         hipLaunchKernelGGL((k_flex_mlp_fwd<NT, NH, true>), dim3((unsigned)grid), dim3(64 * NF_MLP_WAVES), 0, nf_s(stream), packed, ro, rd, depth,
                            n_points, n_samples, depth_per_ray, raw, saved);

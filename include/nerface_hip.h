@@ -310,7 +310,7 @@ int nf_flex_pack(int num_layers, const float* const* params, float* packed, nf_s
 int nf_flex_mlp_fwd(int num_layers, const float* packed, const float* ro, const float* rd, const float* depth, int depth_per_ray,
                     int64_t n_rays, int n_samples, float* raw, nf_stream_t stream);
 size_t nf_flex_saved_floats(int num_layers, int64_t n_points);
-int nf_flex_mlp_fwd_train(int num_layers, const float* packed, const float* ro, const float* rd, const float* depth,
+int nf_flex_mlp_fwd_train(int num_layers, const float* packed, const float* ro, const float* rd, const float* depth,     /* < 2^22 points */
                           int depth_per_ray, int64_t n_rays, int n_samples, float* raw, float* saved, nf_stream_t stream);
 size_t nf_flex_packed_bwd_floats(int num_layers);
 int nf_flex_pack_bwd(int num_layers, const float* const* params, float* packed_t, nf_stream_t stream);

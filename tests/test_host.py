@@ -406,6 +406,9 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device(hip_lib):
     assert lib.nf_paper_bwd_workspace_floats(2048 * 128) > 2176 * 2048 * 128
     assert lib.nf_tiny_bwd_workspace_floats(4096 * 32) > 0
     assert lib.nf_flex_mlp_bwd(4, None, None, None, 4, 4, None, 0, None, None) == EINVAL
+    one = ctypes.c_void_p(16)                                                             # any non-NULL pointer: the size check comes before a launch
+    assert lib.nf_flex_mlp_fwd_train(4, one, one, one, one, 1, 1 << 20, 4, one, one, None) == EINVAL      # 2^22 points: past the 32-bit section offsets
+    assert lib.nf_tiny_mlp_fwd_train(one, one, one, one, 1, 1 << 20, 4, one, one, None) == EINVAL
 
 
 def test_launcher_host_helpers():
