@@ -166,14 +166,18 @@ LCODE_SHAPES = {
 LCODE_KEYS = [k.replace("weight", p) for k in LCODE_SHAPES for p in ("weight", "bias")]
 
 
-def init_lcode_params(seed: int, dtype=torch.float32, boost: bool = True) -> Dict[str, torch.Tensor]:
+def init_lcode_params(seed: int, dtype=torch.float32, boost=True) -> Dict[str, torch.Tensor]:
     g = torch.Generator().manual_seed(seed)
     out: Dict[str, torch.Tensor] = {}
     for k, shp in LCODE_SHAPES.items():
         bound = 1.0 / math.sqrt(shp[1])
         out[k] = ((torch.rand(shp, generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
         out[k.replace("weight", "bias")] = ((torch.rand(shp[0], generator=g, dtype=torch.float64) * 2 - 1) * bound).to(dtype)
-    if boost:
+    if boost == "survey":                       # SURVEY 8(d)'s density head, as init_paper_params: the tight per-stage gates apply
+        out["fc_alpha.weight"] = out["fc_alpha.weight"] * 40.0
+        out["fc_alpha.bias"] = torch.full_like(out["fc_alpha.bias"], 0.5)
+        out["fc_rgb.weight"] = out["fc_rgb.weight"] * 10.0
+    elif boost:
         out["fc_alpha.weight"] = out["fc_alpha.weight"] * 300.0
         out["fc_alpha.bias"] = torch.full_like(out["fc_alpha.bias"], 5.0)
         out["fc_rgb.weight"] = out["fc_rgb.weight"] * 10.0

@@ -1,7 +1,8 @@
 """Seeded fuzz of nerf.run_one_iter_of_nerf (HIP path) against the CPU oracle over the sizes and switches the fixed cases do not reach:
 odd / tiny / large sample counts on both passes (the general-size resample + merge kernel as well as the <= 128 fast path), ray counts
 that leave partial wave tiles and partial workgroups, ragged ray chunks, every sampler / integrator switch (perturb, lindisp, density noise,
-white background, no background prior, coarse only).  SURVEY 8(d)'s density head and SURVEY 8(d)(i)'s gates.  GPU only."""
+white background, no background prior, coarse only), both model families, exact f32 and f16x3.  SURVEY 8(d)'s density head and
+SURVEY 8(d)(i)'s gates.  GPU only."""
 import random
 
 import pytest
@@ -35,9 +36,19 @@ def _configs():
 CONFIGS = _configs()
 
 
-@pytest.mark.parametrize("precision", ["f32", "f16x3"])                   # f16x3 (split-fp16, fp32-class) is held to the f32 gates
+def _lcode_model(nerf, params, device):
+    m = nerf.models.ConditionalBlendshapeLearnableCodeNeRFModel(num_encoding_fn_xyz=10, num_encoding_fn_dir=4, include_input_xyz=True,
+                                                                include_input_dir=False, use_viewdirs=True, num_layers=4, hidden_size=256,
+                                                                include_expression=True)
+    m.load_state_dict(params)
+    return m.to(device)
+
+
+# (family, precision): the paper model in exact f32 and f16x3 (split-fp16, fp32-class: held to the f32 gates); the second family
+# (ConditionalBlendshapeLearnableCodeNeRFModel, M:529-636) with the same density head in both as well
+@pytest.mark.parametrize("family,precision", [("paper", "f32"), ("paper", "f16x3"), ("lcode", "f32"), ("lcode", "f16x3")])
 @pytest.mark.parametrize("k", range(len(CONFIGS)))
-def test_fuzz_against_oracle(hip_lib, gpu, k, precision):
+def test_fuzz_against_oracle(hip_lib, gpu, k, family, precision):
     import nerf
     nerf.set_mlp_precision(precision)
     cfg = dict(CONFIGS[k])
@@ -49,11 +60,14 @@ def test_fuzz_against_oracle(hip_lib, gpu, k, precision):
     finally:
         del C.CASES[name]
     bg = None if no_bg else c["bg"]
+    if family == "lcode":
+        c["p_coarse"], c["p_fine"] = O.init_lcode_params(5, boost="survey"), O.init_lcode_params(6, boost="survey")
+    make, mlp = (_lcode_model, O.lcode_mlp) if family == "lcode" else (U.make_model, None)
     ref = O.render_rays(c["p_coarse"], c["p_fine"], c["ro"], c["rd"], c["expr"], c["latent"], bg, O.NEAR, O.FAR, c["n_coarse"], c["n_fine"],
                         t_rand=c["t_rand"], noise_c=c["noise_c"], u=c["u"], noise_f=c["noise_f"], lindisp=bool(c.get("lindisp", False)),
-                        white_background=white)
-    mc = U.make_model(nerf, c["p_coarse"], gpu)
-    mf = U.make_model(nerf, c["p_fine"], gpu) if c["n_fine"] > 0 else None
+                        white_background=white, mlp=mlp)
+    mc = make(nerf, c["p_coarse"], gpu)
+    mf = make(nerf, c["p_fine"], gpu) if c["n_fine"] > 0 else None
     opt = U.make_options(nerf, c["n_coarse"], c["n_fine"], bool(c["stochastic"]), c["noise_std"], chunk or 65536, white=white,
                          lindisp=bool(c.get("lindisp", False)))
     ex, ed = U.encoders(nerf)
@@ -71,6 +85,6 @@ def test_fuzz_against_oracle(hip_lib, gpu, k, precision):
         assert got is not None and tuple(got.shape) == tuple(want.shape), (n, desc)
         assert bool(torch.isfinite(got).all()), (n, desc)
         worst[n] = float((got.cpu() - want).abs().max())
-    print(f"[fuzz {k} {precision}] {desc}: " + " ".join(f"{n}={v:.1e}" for n, v in worst.items()))
+    print(f"[fuzz {k} {family} {precision}] {desc}: " + " ".join(f"{n}={v:.1e}" for n, v in worst.items()))
     for n, v in worst.items():
         assert v <= GATE[n], (n, v, desc)
