@@ -88,3 +88,83 @@ def test_fuzz_against_oracle(hip_lib, gpu, k, family, precision):
     print(f"[fuzz {k} {family} {precision}] {desc}: " + " ".join(f"{n}={v:.1e}" for n, v in worst.items()))
     for n, v in worst.items():
         assert v <= GATE[n], (n, v, desc)
+
+
+# ---- the training step on sizes the fixed cases do not reach ---------------------------------------------------------------------------
+def _grad_configs():
+    rnd = random.Random(77)
+    out = []
+    for k in range(6):
+        out.append(dict(frame=rnd.randrange(0, 400), n_rays=rnd.choice([5, 33, 65, 127, 200]), n_coarse=rnd.choice([8, 33, 64, 100]),
+                        n_fine=rnd.choice([0, 7, 31, 64, 129]), stochastic=True, noise_std=rnd.choice([0.0, 0.1]), boost="survey",
+                        lindisp=rnd.random() < 0.3))
+    return out
+
+
+GRAD_CONFIGS = _grad_configs()
+
+
+@pytest.mark.parametrize("family", ["paper", "lcode"])
+@pytest.mark.parametrize("k", range(len(GRAD_CONFIGS)))
+def test_fuzz_training_step_gradients(hip_lib, gpu, k, family):
+    """loss.backward() through run_one_iter_of_nerf (mode train, exact f32) on drawn sizes -- odd ray counts (partial wave tiles, ragged
+    point slices of the weight-gradient GEMMs), odd / large sample counts, coarse only -- against the oracle's autograd in float64 on the
+    same draws.  Gates as tests/test_gpu_backward.py's end-to-end step: fp32 and fp64 differ by the odd ReLU unit whose input rounds across
+    zero (each flip moves the tensors of its layer and the ones below it), so the MEDIAN tensor carries the gate (2e-4), the worst is
+    bounded loosely (2e-2) and at most 4 tensors may sit above 1.5e-3; loss to 2e-6, latent gradient to 1e-4 where every tensor is within
+    1e-4 (no flip), else 2e-3."""
+    import nerf
+    cfg = dict(GRAD_CONFIGS[k])
+    name = f"gfuzz_{k}"
+    C.CASES[name] = cfg
+    try:
+        c = C.build_case(name)
+    finally:
+        del C.CASES[name]
+    if family == "lcode":
+        c["p_coarse"], c["p_fine"] = O.init_lcode_params(5, boost="survey"), O.init_lcode_params(6, boost="survey")
+    make, mlp = (_lcode_model, O.lcode_mlp) if family == "lcode" else (U.make_model, None)
+    nc, nf = c["n_coarse"], c["n_fine"]
+    mc = make(nerf, c["p_coarse"], gpu)
+    mf = make(nerf, c["p_fine"], gpu) if nf > 0 else None
+    opt = U.make_options(nerf, nc, nf, True, c["noise_std"], 65536, lindisp=bool(c.get("lindisp", False)))
+    ex, ed = U.encoders(nerf)
+    rands, randns = U.case_random_lists(c)
+    latent = c["latent"].clone().to(gpu).requires_grad_(True)
+    with U.injected_random(rands, randns):
+        out = nerf.run_one_iter_of_nerf(512, 512, None, mc, mf, c["ro"].to(gpu), c["rd"].to(gpu), opt, mode="train", encode_position_fn=ex,
+                                        encode_direction_fn=ed, expressions=c["expr"].to(gpu), background_prior=c["bg"].to(gpu),
+                                        latent_code=latent)
+    tgt = c["tgt"].to(gpu)
+    loss = O.train_loss(out[0], out[3] if nf > 0 else out[0], tgt, latent) if nf > 0 else \
+        torch.nn.functional.mse_loss(out[0][..., :3], tgt[..., :3]) + 0.005 * torch.norm(latent)
+    loss.backward()
+    d = lambda t: None if t is None else t.double()
+    pc = {kk: v.double().clone().requires_grad_(True) for kk, v in c["p_coarse"].items()}
+    pf = {kk: v.double().clone().requires_grad_(True) for kk, v in c["p_fine"].items()}
+    lat = c["latent"].double().clone().requires_grad_(True)
+    o = O.render_rays(pc, pf, d(c["ro"]), d(c["rd"]), d(c["expr"]), lat, d(c["bg"]), O.NEAR, O.FAR, nc, nf, t_rand=d(c["t_rand"]),
+                      noise_c=d(c["noise_c"]), u=d(c["u"]), noise_f=d(c["noise_f"]), lindisp=bool(c.get("lindisp", False)), mlp=mlp)
+    ref_loss = O.train_loss(o[0], o[3], d(c["tgt"]), lat) if nf > 0 else \
+        torch.nn.functional.mse_loss(o[0][..., :3], d(c["tgt"])[..., :3]) + 0.005 * torch.norm(lat)
+    ref_loss.backward()
+    rel = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    errs = []
+    for m, po in ((mc, pc), (mf, pf)):
+        if m is None:
+            continue
+        for kk, v in m.named_parameters():
+            if po[kk].grad is None or float(po[kk].grad.abs().max()) == 0.0:
+                assert v.grad is None or float(v.grad.abs().max()) == 0.0, kk           # dead tensors (Q3) stay dead
+                continue
+            assert v.grad is not None and bool(torch.isfinite(v.grad).all()), kk
+            errs.append(rel(v.grad.cpu(), po[kk].grad))
+    errs.sort()
+    e_lat = rel(latent.grad.cpu(), lat.grad)
+    desc = {kk: v for kk, v in GRAD_CONFIGS[k].items() if kk != "boost"}
+    n_loose = sum(e >= 1.5e-3 for e in errs)
+    print(f"[grad fuzz {k} {family}] {desc}: loss {float(loss):.6f} vs {float(ref_loss):.6f}; {len(errs)} tensors, median {errs[len(errs) // 2]:.1e}, "
+          f"worst {errs[-1]:.1e}, above 1.5e-3: {n_loose}; latent {e_lat:.1e}")
+    assert abs(float(loss) - float(ref_loss)) <= 2e-6 * max(1.0, abs(float(ref_loss)))
+    assert errs[len(errs) // 2] < 2e-4 and errs[-1] < 2e-2 and n_loose <= 4, errs[-6:]
+    assert e_lat < (1e-4 if errs[-1] < 1e-4 else 2e-3), e_lat            # (a flipped unit anywhere moves the latent row's gradient with it)
